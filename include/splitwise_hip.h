@@ -1,0 +1,131 @@
+/*
+ * splitwise_hip.h -- C ABI of libsplitwise_hip.so (gfx950 / MI355X).
+ *
+ * One `extern "C"` entry point per native operator that the reference binds
+ * through pybind (`csrc/pybind.cpp:6-129`) or JIT-compiles for its KV transport
+ * (`vllm/worker/comm_utils.py:22-87`).  Signatures carry raw device pointers,
+ * explicit shapes / strides (in ELEMENTS unless a name ends in `_bytes`), dtype
+ * enums and the HIP stream to enqueue on.  No torch types.
+ *
+ * Conventions
+ *   - every function returns SW_OK (0) or a negative sw_status; the message of
+ *     the last failure on the calling thread is returned by sw_last_error().
+ *   - launches are asynchronous on `stream` (a hipStream_t passed as void*,
+ *     NULL = the default stream) on the CURRENT device of the calling thread;
+ *     nothing synchronises unless the comment says so.
+ *   - tensors are borrowed for the duration of the call only; the caller
+ *     allocates every output.
+ *   - thread safe: no global mutable state except the per-thread error string.
+ */
+#ifndef SPLITWISE_HIP_H_
+#define SPLITWISE_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum sw_status {
+  SW_OK = 0,
+  SW_ERR_INVALID = -1,     /* unsupported head size / block size / dtype / bad shape:
+                              the reference raises RuntimeError via TORCH_CHECK
+                              (csrc/attention/attention_kernels.cu:675,707,732,745) */
+  SW_ERR_HIP = -2,         /* a HIP runtime call failed */
+  SW_ERR_TIMEOUT = -3      /* host-side wait ran out (only sw_kv_flag_wait_host) */
+} sw_status;
+
+typedef enum sw_dtype {
+  SW_F32 = 0,
+  SW_F16 = 1,
+  SW_BF16 = 2,
+  SW_FP8_E5M2 = 3          /* unscaled e5m2 stored as uint8 (kv_cache_dtype "fp8_e5m2") */
+} sw_dtype;
+
+const char* sw_last_error(void);
+int sw_abi_version(void);
+
+/* csrc/cuda_utils_kernels.cu:16-35 get_max_shared_memory_per_block_device_attribute:
+ * LDS bytes one workgroup may use on `device`. */
+int sw_get_max_shared_memory_per_block(int device, int* out_bytes);
+
+/* ------------------------------------------------------------------ cache ops
+ * csrc/cache_kernels.cu:228-268 reshape_and_cache.
+ *   key/value      [num_tokens, num_heads, head_size] act_dtype, token stride
+ *                  key_stride / value_stride (sliced out of a fused qkv tensor)
+ *   key_cache      [num_blocks, num_heads, head_size/x, block_size, x]
+ *   value_cache    [num_blocks, num_heads, head_size, block_size]
+ *   slot_mapping   int64 [num_tokens]; negative slot = padding, skipped
+ *   cache_dtype    == act_dtype ("auto") or SW_FP8_E5M2
+ *   x              16 / sizeof(cache element)                              */
+int sw_reshape_and_cache(const void* key, const void* value, void* key_cache,
+                         void* value_cache, const int64_t* slot_mapping,
+                         int num_tokens, int num_heads, int head_size,
+                         int block_size, int x, int64_t key_stride,
+                         int64_t value_stride, int act_dtype, int cache_dtype,
+                         void* stream);
+
+/* csrc/cache_kernels.cu:95-150 copy_blocks.  For every layer l and every pair p:
+ * block dst[p] of key_cache_ptrs[l] and of value_cache_ptrs[l] := block src[p].
+ *   key_cache_ptrs / value_cache_ptrs  DEVICE arrays of num_layers device pointers
+ *   block_mapping                      DEVICE int64 [num_pairs][2] = (src, dst)
+ *   block_bytes                        bytes of one block of one tensor, multiple of 16 */
+int sw_copy_blocks(const void* const* key_cache_ptrs,
+                   const void* const* value_cache_ptrs, int num_layers,
+                   const int64_t* block_mapping, int num_pairs,
+                   int64_t block_bytes, void* stream);
+
+/* csrc/cache_kernels.cu:21-60 swap_blocks.  HOST arrays src_blocks/dst_blocks of
+ * n entries; one async copy per maximal run of consecutive (src,dst) numbers.
+ *   kind: 0 = device->device (same GPU), 1 = device->host, 2 = host->device  */
+int sw_swap_blocks(const void* src, void* dst, const int64_t* src_blocks,
+                   const int64_t* dst_blocks, int n, int64_t block_bytes,
+                   int kind, void* stream);
+
+/* csrc/cache_kernels.cu:296-320 convert_fp8_e5m2: elementwise cast of `numel`
+ * elements.  Exactly one of src_dtype / dst_dtype is SW_FP8_E5M2.
+ * to-fp8 is round-to-nearest-even, saturating to +-57344; NaN -> sign|0x7F
+ * (csrc/quantization/fp8_e5m2_kvcache/quant_utils.cuh:164-192).             */
+int sw_convert_fp8_e5m2(const void* src, void* dst, int64_t numel,
+                        int src_dtype, int dst_dtype, void* stream);
+
+/* ------------------------------------------------------------ paged attention
+ * csrc/attention/attention_kernels.cu:711-747 paged_attention_v1.
+ *   out            [num_seqs, num_heads, head_size] act_dtype, contiguous
+ *   query          [num_seqs, num_heads, head_size], seq stride q_stride
+ *   key_cache / value_cache as above; kv_block_stride / kv_head_stride in elements
+ *   block_tables   int32 [num_seqs, max_num_blocks_per_seq]
+ *   context_lens   int32 [num_seqs]
+ *   alibi_slopes   float [num_heads] or NULL
+ * head_size in {64,80,96,112,128,256}, block_size in {8,16,32}.            */
+int sw_paged_attention_v1(void* out, const void* query, const void* key_cache,
+                          const void* value_cache, int num_seqs, int num_heads,
+                          int num_kv_heads, int head_size, float scale,
+                          const int32_t* block_tables,
+                          const int32_t* context_lens, int block_size,
+                          int max_context_len, int max_num_blocks_per_seq,
+                          const float* alibi_slopes, int64_t q_stride,
+                          int64_t kv_block_stride, int64_t kv_head_stride,
+                          int act_dtype, int cache_dtype, void* stream);
+
+/* csrc/attention/attention_kernels.cu:901-940 paged_attention_v2: the context is
+ * split into partitions of 512 tokens.
+ *   exp_sums, max_logits  float [num_seqs, num_heads, max_num_partitions]
+ *   tmp_out               act_dtype [num_seqs, num_heads, max_num_partitions, head_size]
+ *   max_num_partitions    = ceil(max_context_len / 512)                   */
+int sw_paged_attention_v2(void* out, float* exp_sums, float* max_logits,
+                          void* tmp_out, const void* query,
+                          const void* key_cache, const void* value_cache,
+                          int num_seqs, int num_heads, int num_kv_heads,
+                          int head_size, float scale,
+                          const int32_t* block_tables,
+                          const int32_t* context_lens, int block_size,
+                          int max_context_len, int max_num_blocks_per_seq,
+                          const float* alibi_slopes, int64_t q_stride,
+                          int64_t kv_block_stride, int64_t kv_head_stride,
+                          int act_dtype, int cache_dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPLITWISE_HIP_H_ */

@@ -1,0 +1,159 @@
+"""GPU parity: paged_attention_v1 / v2 through the C ABI vs the CPU oracle and vs the
+fixtures produced by the reference's own test reference.
+
+Mirrors tests/kernels/test_attention.py:114-269 of the reference: 7 sequences, heads
+(40, 40) and (64, 8), every supported head size, block sizes 16 / 32 (and 8), ALiBi on
+and off, kv cache "auto" and "fp8_e5m2".  Tolerance is the reference's: atol 1e-3,
+rtol 1e-5 (fp8 cache: atol 1e-2), tests/kernels/test_attention.py:262-269.
+"""
+import glob
+import os
+import random
+
+import pytest
+import torch
+
+from helpers import DTYPES, GOLDEN, from_np, load_golden, make_kv_caches
+from oracle import attention as oattn
+
+pytestmark = pytest.mark.gpu
+
+PARTITION_SIZE = 512
+NUM_BLOCKS = 1024
+PAGED = sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, "paged_attention_*.npz")))
+
+
+def _C():
+    from splitwise_amd import _C
+    return _C
+
+
+def run_kernel(version, query, kc, vc, num_kv_heads, scale, block_tables, context_lens, block_size,
+               alibi, kv_cache_dtype):
+    C = _C()
+    out = torch.empty_like(query)
+    max_ctx = int(context_lens.max().item())
+    if version == "v1":
+        C.ops.paged_attention_v1(out, query, kc, vc, num_kv_heads, scale, block_tables, context_lens,
+                                 block_size, max_ctx, alibi, kv_cache_dtype)
+    else:
+        num_seqs, num_heads, head_size = query.shape
+        parts = (max_ctx + PARTITION_SIZE - 1) // PARTITION_SIZE
+        tmp = torch.empty(num_seqs, num_heads, parts, head_size, dtype=query.dtype, device=query.device)
+        exp_sums = torch.empty(num_seqs, num_heads, parts, dtype=torch.float32, device=query.device)
+        max_logits = torch.empty_like(exp_sums)
+        C.ops.paged_attention_v2(out, exp_sums, max_logits, tmp, query, kc, vc, num_kv_heads, scale,
+                                 block_tables, context_lens, block_size, max_ctx, alibi, kv_cache_dtype)
+    torch.cuda.synchronize()
+    return out
+
+
+@pytest.mark.parametrize("version", ["v1", "v2"])
+@pytest.mark.parametrize("name", PAGED)
+def test_against_reference_fixture(version, name):
+    z = load_golden(name)
+    dtype = DTYPES[str(z["dtype"])]
+    q = from_np(z["query"], dtype).cuda()
+    kc, vc = from_np(z["key_cache"], dtype).cuda(), from_np(z["value_cache"], dtype).cuda()
+    slopes = torch.from_numpy(z["alibi_slopes"]).cuda() if z["alibi_slopes"].size else None
+    out = run_kernel(version, q, kc, vc, int(z["num_kv_heads"]), float(z["scale"]),
+                     torch.from_numpy(z["block_tables"]).cuda(), torch.from_numpy(z["context_lens"]).cuda(),
+                     int(z["block_size"]), slopes, "auto")
+    torch.testing.assert_close(out.cpu().float(), from_np(z["out"], dtype).float(), atol=1e-3, rtol=1e-5)
+
+
+@pytest.mark.parametrize("version", ["v1", "v2"])
+@pytest.mark.parametrize("num_heads", [(40, 40), (64, 8)])
+@pytest.mark.parametrize("head_size", [64, 80, 96, 112, 128, 256])
+@pytest.mark.parametrize("use_alibi", [False, True])
+@pytest.mark.parametrize("block_size", [16, 32])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("kv_cache_dtype", ["auto", "fp8_e5m2"])
+def test_paged_attention(version, num_heads, head_size, use_alibi, block_size, dtype, kv_cache_dtype):
+    random.seed(0)
+    torch.manual_seed(0)
+    num_seqs, max_seq_len = 7, 1500
+    num_query_heads, num_kv_heads = num_heads
+    scale = float(1.0 / head_size ** 0.5)
+    query = torch.empty(num_seqs, num_query_heads, head_size, dtype=dtype).uniform_(-scale, scale)
+    alibi = torch.randn(num_query_heads, dtype=torch.float) if use_alibi else None
+    context_lens = [random.randint(1, max_seq_len) for _ in range(num_seqs)]
+    context_lens[-1] = max_seq_len
+    context_lens[0] = 1
+    max_blocks = (max_seq_len + block_size - 1) // block_size
+    tables = [[random.randint(0, NUM_BLOCKS - 1) for _ in range(max_blocks)] for _ in range(num_seqs)]
+    block_tables = torch.tensor(tables, dtype=torch.int)
+    context_lens = torch.tensor(context_lens, dtype=torch.int)
+    kc, vc = make_kv_caches(NUM_BLOCKS, block_size, num_kv_heads, head_size, dtype, cache_dtype=kv_cache_dtype)
+
+    ref = oattn.paged_attention(query, kc, vc, block_tables, context_lens, scale, alibi)
+    out = run_kernel(version, query.cuda(), kc.cuda(), vc.cuda(), num_kv_heads, scale, block_tables.cuda(),
+                     context_lens.cuda(), block_size, alibi.cuda() if use_alibi else None, kv_cache_dtype)
+    atol = 1e-2 if kv_cache_dtype == "fp8_e5m2" else 1e-3
+    torch.testing.assert_close(out.cpu().float(), ref.float(), atol=atol, rtol=1e-5)
+
+
+@pytest.mark.parametrize("version", ["v1", "v2"])
+@pytest.mark.parametrize("dtype,block_size,head_size,heads", [
+    (torch.float32, 16, 128, (8, 8)), (torch.float32, 32, 80, (8, 2)), (torch.float32, 8, 64, (4, 4)),
+    (torch.float16, 8, 128, (8, 4)), (torch.bfloat16, 8, 96, (4, 4))])
+@pytest.mark.parametrize("kv_cache_dtype", ["auto", "fp8_e5m2"])
+def test_paged_attention_other_layouts(version, dtype, block_size, head_size, heads, kv_cache_dtype):
+    random.seed(1)
+    torch.manual_seed(1)
+    h, kvh = heads
+    num_seqs, max_seq_len, nb = 5, 700, 256
+    scale = float(1.0 / head_size ** 0.5)
+    query = torch.empty(num_seqs, h, head_size, dtype=dtype).uniform_(-scale, scale)
+    context_lens = torch.tensor([random.randint(1, max_seq_len) for _ in range(num_seqs - 1)] + [max_seq_len],
+                                dtype=torch.int)
+    max_blocks = (max_seq_len + block_size - 1) // block_size
+    block_tables = torch.tensor([[random.randint(0, nb - 1) for _ in range(max_blocks)] for _ in range(num_seqs)],
+                                dtype=torch.int)
+    kc, vc = make_kv_caches(nb, block_size, kvh, head_size, dtype, cache_dtype=kv_cache_dtype)
+    ref = oattn.paged_attention(query, kc, vc, block_tables, context_lens, scale, None)
+    out = run_kernel(version, query.cuda(), kc.cuda(), vc.cuda(), kvh, scale, block_tables.cuda(),
+                     context_lens.cuda(), block_size, None, kv_cache_dtype)
+    atol = 1e-2 if kv_cache_dtype == "fp8_e5m2" else 1e-3
+    torch.testing.assert_close(out.cpu().float(), ref.float(), atol=atol, rtol=1e-5)
+
+
+def test_strided_query_and_nan_tail():
+    """The query is a slice of a fused qkv tensor (q_stride != H*D), and the unused tail of
+    the last block holds NaNs that must not leak (attention_kernels.cu:342-351)."""
+    torch.manual_seed(0)
+    dtype, h, kvh, d, bs, nb = torch.bfloat16, 8, 8, 128, 16, 64
+    scale = d ** -0.5
+    qkv = torch.empty(3, 3 * h * d, dtype=dtype).uniform_(-scale, scale)
+    query = qkv[:, :h * d].view(3, h, d)
+    kc, vc = make_kv_caches(nb, bs, kvh, d, dtype)
+    context_lens = torch.tensor([5, 37, 130], dtype=torch.int)
+    block_tables = torch.tensor([[1, 0, 0, 0, 0, 0, 0, 0, 0], [2, 3, 4, 0, 0, 0, 0, 0, 0],
+                                 [5, 6, 7, 8, 9, 10, 11, 12, 13]], dtype=torch.int)
+    for seq, ctx in enumerate(context_lens.tolist()):          # poison what lies past the context
+        last = block_tables[seq, (ctx - 1) // bs]
+        kc[last, :, :, ctx % bs:, :] = float("nan")
+        vc[last, :, :, ctx % bs:] = float("nan")
+    ref = oattn.paged_attention(query, kc, vc, block_tables, context_lens, scale)
+    assert not torch.isnan(ref).any()
+    qd = qkv.cuda()[:, :h * d].view(3, h, d)
+    for version in ("v1", "v2"):
+        out = run_kernel(version, qd, kc.cuda(), vc.cuda(), kvh, scale, block_tables.cuda(),
+                         context_lens.cuda(), bs, None, "auto")
+        torch.testing.assert_close(out.cpu().float(), ref.float(), atol=1e-3, rtol=1e-5)
+
+
+def test_unsupported_shapes_raise():
+    C = _C()
+    q = torch.zeros(1, 4, 72, dtype=torch.float16, device="cuda")
+    kc = torch.zeros(2, 4, 9, 16, 8, dtype=torch.float16, device="cuda")
+    vc = torch.zeros(2, 4, 72, 16, dtype=torch.float16, device="cuda")
+    bt = torch.zeros(1, 1, dtype=torch.int, device="cuda")
+    cl = torch.ones(1, dtype=torch.int, device="cuda")
+    with pytest.raises(RuntimeError, match="Unsupported head size"):
+        C.ops.paged_attention_v1(torch.empty_like(q), q, kc, vc, 4, 1.0, bt, cl, 16, 1, None, "auto")
+    q = torch.zeros(1, 4, 64, dtype=torch.float16, device="cuda")
+    kc = torch.zeros(2, 4, 8, 4, 8, dtype=torch.float16, device="cuda")
+    vc = torch.zeros(2, 4, 64, 4, dtype=torch.float16, device="cuda")
+    with pytest.raises(RuntimeError, match="Unsupported block size"):
+        C.ops.paged_attention_v1(torch.empty_like(q), q, kc, vc, 4, 1.0, bt, cl, 4, 1, None, "auto")

@@ -1,0 +1,7 @@
+// Paged-attention instantiations for activations=f16_t, fp8-e5m2 cache=false.
+// Split per (activation, cache) pair so the translation units build in parallel.
+#include "paged_attention.cuh"
+
+namespace sw {
+int pa_dispatch_f16(const PaArgs& a) { return dispatch_pa<f16_t, false, true>(a); }
+}  // namespace sw

@@ -1,0 +1,7 @@
+// Paged-attention instantiations for activations=float, fp8-e5m2 cache=false.
+// Split per (activation, cache) pair so the translation units build in parallel.
+#include "paged_attention.cuh"
+
+namespace sw {
+int pa_dispatch_f32(const PaArgs& a) { return dispatch_pa<float, false, false>(a); }
+}  // namespace sw

@@ -1,0 +1,287 @@
+"""ctypes binding of libsplitwise_hip.so with the reference's operator table.
+
+The reference exposes its native operators as ``vllm._C.{ops,cache_ops,cuda_utils}``
+(``csrc/pybind.cpp:6-129``).  This module offers the same three namespaces with the
+same function names and argument order, so callers written against the reference
+(`PagedAttentionImpl`, `CacheEngine`, the kernel tests) run unchanged; underneath,
+every call goes through the C ABI declared in ``include/splitwise_hip.h`` with raw
+device pointers, explicit strides and torch's current HIP stream.
+
+There is no fallback: if the shared library is missing or an entry point fails,
+the call raises ``RuntimeError`` (the reference raises the same type through
+``TORCH_CHECK``).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from types import SimpleNamespace
+from typing import Dict, List, Optional
+
+import torch
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libsplitwise_hip.so")
+
+SW_F32, SW_F16, SW_BF16, SW_FP8_E5M2 = 0, 1, 2, 3
+_TORCH_TO_SW = {torch.float32: SW_F32, torch.float16: SW_F16, torch.bfloat16: SW_BF16}
+
+_c_void_p = ctypes.c_void_p
+_c_int = ctypes.c_int
+_c_i64 = ctypes.c_int64
+_c_float = ctypes.c_float
+
+# name -> argtypes; mirrors include/splitwise_hip.h one to one
+_SIGNATURES = {
+    "sw_abi_version": [],
+    "sw_get_max_shared_memory_per_block": [_c_int, ctypes.POINTER(_c_int)],
+    "sw_reshape_and_cache": [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int,
+                             _c_int, _c_int, _c_int, _c_i64, _c_i64, _c_int, _c_int, _c_void_p],
+    "sw_copy_blocks": [_c_void_p, _c_void_p, _c_int, _c_void_p, _c_int, _c_i64, _c_void_p],
+    "sw_swap_blocks": [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_i64, _c_int, _c_void_p],
+    "sw_convert_fp8_e5m2": [_c_void_p, _c_void_p, _c_i64, _c_int, _c_int, _c_void_p],
+    "sw_paged_attention_v1": [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int,
+                              _c_float, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p,
+                              _c_i64, _c_i64, _c_i64, _c_int, _c_int, _c_void_p],
+    "sw_paged_attention_v2": [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
+                              _c_int, _c_int, _c_int, _c_int, _c_float, _c_void_p, _c_void_p, _c_int,
+                              _c_int, _c_int, _c_void_p, _c_i64, _c_i64, _c_i64, _c_int, _c_int,
+                              _c_void_p],
+}
+
+_lib = None
+
+
+def library_path() -> str:
+    return _LIB_PATH
+
+
+def load_library() -> ctypes.CDLL:
+    """Loads the native library once; raises RuntimeError when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise RuntimeError(
+            f"native library not built: {_LIB_PATH} is missing "
+            "(run `make -C vllm-splitwise_amd` or `python -c 'import __graft_entry__ as g; g.build()'`)")
+    lib = ctypes.CDLL(_LIB_PATH)
+    lib.sw_last_error.restype = ctypes.c_char_p
+    lib.sw_last_error.argtypes = []
+    for name, argtypes in _SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = _c_int
+    _lib = lib
+    return lib
+
+
+def exported_symbols() -> List[str]:
+    return ["sw_last_error"] + list(_SIGNATURES)
+
+
+def _check(status: int) -> None:
+    if status != 0:
+        msg = load_library().sw_last_error().decode("utf-8", "replace")
+        raise RuntimeError(msg or f"splitwise_hip call failed with status {status}")
+
+
+def _stream(t: torch.Tensor) -> int:
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _act_dtype(t: torch.Tensor) -> int:
+    try:
+        return _TORCH_TO_SW[t.dtype]
+    except KeyError:
+        raise RuntimeError(f"Unsupported data type: {t.dtype}") from None
+
+
+def _cache_dtype(kv_cache_dtype: str, act: int) -> int:
+    if kv_cache_dtype == "auto":
+        return act
+    if kv_cache_dtype == "fp8_e5m2":
+        return SW_FP8_E5M2
+    raise RuntimeError(f"Unsupported data type of kv cache: {kv_cache_dtype}")
+
+
+def _require_cuda(*tensors: torch.Tensor) -> None:
+    for t in tensors:
+        if not t.is_cuda:
+            raise RuntimeError("splitwise_hip operators need tensors on a HIP device")
+
+
+# --------------------------------------------------------------------- cache_ops
+def reshape_and_cache(key: torch.Tensor, value: torch.Tensor, key_cache: torch.Tensor,
+                      value_cache: torch.Tensor, slot_mapping: torch.Tensor,
+                      kv_cache_dtype: str) -> None:
+    """``cache_ops.reshape_and_cache`` (csrc/cache_kernels.cu:228-268)."""
+    _require_cuda(key, value, key_cache, value_cache, slot_mapping)
+    act = _act_dtype(key)
+    cache = _cache_dtype(kv_cache_dtype, act)
+    num_tokens, num_heads, head_size = key.shape
+    block_size, x = key_cache.shape[3], key_cache.shape[4]
+    if key.stride(2) != 1 or key.stride(1) != head_size or value.stride(2) != 1 or value.stride(1) != head_size:
+        raise RuntimeError("reshape_and_cache: key/value heads must be contiguous")
+    if slot_mapping.dtype != torch.int64:
+        raise RuntimeError("reshape_and_cache: slot_mapping must be int64")
+    with torch.cuda.device(key.device):
+        _check(load_library().sw_reshape_and_cache(
+            key.data_ptr(), value.data_ptr(), key_cache.data_ptr(), value_cache.data_ptr(),
+            slot_mapping.data_ptr(), num_tokens, num_heads, head_size, block_size, x,
+            key.stride(0), value.stride(0), act, cache, _stream(key)))
+
+
+_ptr_table_cache: Dict[tuple, torch.Tensor] = {}
+
+
+def _ptr_table(tensors: List[torch.Tensor]) -> torch.Tensor:
+    """Device array of the tensors' base pointers; uploaded once per distinct list."""
+    key = (tensors[0].device.index,) + tuple(t.data_ptr() for t in tensors)
+    tab = _ptr_table_cache.get(key)
+    if tab is None:
+        if len(_ptr_table_cache) > 64:
+            _ptr_table_cache.clear()
+        tab = torch.tensor([t.data_ptr() for t in tensors], dtype=torch.int64, device=tensors[0].device)
+        _ptr_table_cache[key] = tab
+    return tab
+
+
+def copy_blocks(key_caches: List[torch.Tensor], value_caches: List[torch.Tensor],
+                block_mapping: Dict[int, List[int]]) -> None:
+    """``cache_ops.copy_blocks`` (csrc/cache_kernels.cu:95-150)."""
+    num_layers = len(key_caches)
+    if num_layers != len(value_caches):
+        raise RuntimeError("copy_blocks: key_caches and value_caches differ in length")
+    if num_layers == 0:
+        return
+    _require_cuda(key_caches[0], value_caches[0])
+    pairs = [(src, dst) for src, dsts in block_mapping.items() for dst in dsts]
+    if not pairs:
+        return
+    dev = key_caches[0].device
+    block_bytes = key_caches[0][0].numel() * key_caches[0].element_size()
+    mapping = torch.tensor(pairs, dtype=torch.int64).to(dev, non_blocking=False)
+    with torch.cuda.device(dev):
+        _check(load_library().sw_copy_blocks(
+            _ptr_table(key_caches).data_ptr(), _ptr_table(value_caches).data_ptr(), num_layers,
+            mapping.data_ptr(), len(pairs), block_bytes, _stream(key_caches[0])))
+        # `mapping` is consumed asynchronously: keep it alive until the stream passes it
+        mapping.record_stream(torch.cuda.current_stream(dev))
+
+
+def swap_blocks(src: torch.Tensor, dst: torch.Tensor, block_mapping: Dict[int, int]) -> None:
+    """``cache_ops.swap_blocks`` (csrc/cache_kernels.cu:21-60)."""
+    if src.is_cuda and dst.is_cuda:
+        if src.device != dst.device:
+            raise RuntimeError("src and dst must be on the same GPU")
+        kind, dev = 0, src.device
+    elif src.is_cuda and not dst.is_cuda:
+        kind, dev = 1, src.device
+    elif not src.is_cuda and dst.is_cuda:
+        kind, dev = 2, dst.device
+    else:
+        raise RuntimeError("Invalid device combination")
+    if not block_mapping:
+        return
+    items = sorted(block_mapping.items())
+    n = len(items)
+    src_blocks = (ctypes.c_int64 * n)(*[s for s, _ in items])
+    dst_blocks = (ctypes.c_int64 * n)(*[d for _, d in items])
+    block_bytes = src[0].numel() * src.element_size()
+    with torch.cuda.device(dev):
+        _check(load_library().sw_swap_blocks(
+            src.data_ptr(), dst.data_ptr(), ctypes.addressof(src_blocks), ctypes.addressof(dst_blocks),
+            n, block_bytes, kind, torch.cuda.current_stream(dev).cuda_stream))
+
+
+def convert_fp8_e5m2(src_cache: torch.Tensor, dst_cache: torch.Tensor) -> None:
+    """``cache_ops.convert_fp8_e5m2`` (csrc/cache_kernels.cu:296-320)."""
+    _require_cuda(src_cache, dst_cache)
+    if not (src_cache.is_contiguous() and dst_cache.is_contiguous()):
+        raise RuntimeError("convert_fp8_e5m2: tensors must be contiguous")
+    if src_cache.numel() != dst_cache.numel():
+        raise RuntimeError("convert_fp8_e5m2: size mismatch")
+    sdt = SW_FP8_E5M2 if src_cache.dtype == torch.uint8 else _act_dtype(src_cache)
+    ddt = SW_FP8_E5M2 if dst_cache.dtype == torch.uint8 else _act_dtype(dst_cache)
+    with torch.cuda.device(src_cache.device):
+        _check(load_library().sw_convert_fp8_e5m2(
+            src_cache.data_ptr(), dst_cache.data_ptr(), src_cache.numel(), sdt, ddt, _stream(src_cache)))
+
+
+# --------------------------------------------------------------------------- ops
+def _pa_common(query, key_cache, value_cache, block_tables, context_lens, alibi_slopes):
+    _require_cuda(query, key_cache, value_cache, block_tables, context_lens)
+    if block_tables.dtype != torch.int32 or context_lens.dtype != torch.int32:
+        raise RuntimeError("paged_attention: block_tables and context_lens must be int32")
+    if not block_tables.is_contiguous() and block_tables.stride(1) != 1:
+        raise RuntimeError("paged_attention: block_tables rows must be contiguous")
+    if alibi_slopes is not None:
+        if alibi_slopes.dtype != torch.float32:
+            raise RuntimeError("paged_attention: alibi_slopes must be float32")
+        if not alibi_slopes.is_cuda:
+            alibi_slopes = alibi_slopes.to(query.device)
+    return alibi_slopes
+
+
+def paged_attention_v1(out: torch.Tensor, query: torch.Tensor, key_cache: torch.Tensor,
+                       value_cache: torch.Tensor, num_kv_heads: int, scale: float,
+                       block_tables: torch.Tensor, context_lens: torch.Tensor, block_size: int,
+                       max_context_len: int, alibi_slopes: Optional[torch.Tensor],
+                       kv_cache_dtype: str) -> None:
+    """``ops.paged_attention_v1`` (csrc/attention/attention_kernels.cu:711-747)."""
+    alibi_slopes = _pa_common(query, key_cache, value_cache, block_tables, context_lens, alibi_slopes)
+    act = _act_dtype(query)
+    cache = _cache_dtype(kv_cache_dtype, act)
+    num_seqs, num_heads, head_size = query.shape
+    with torch.cuda.device(query.device):
+        _check(load_library().sw_paged_attention_v1(
+            out.data_ptr(), query.data_ptr(), key_cache.data_ptr(), value_cache.data_ptr(),
+            num_seqs, num_heads, num_kv_heads, head_size, float(scale), block_tables.data_ptr(),
+            context_lens.data_ptr(), block_size, int(max_context_len), block_tables.stride(0),
+            alibi_slopes.data_ptr() if alibi_slopes is not None else None, query.stride(0),
+            key_cache.stride(0), key_cache.stride(1), act, cache, _stream(query)))
+
+
+def paged_attention_v2(out: torch.Tensor, exp_sums: torch.Tensor, max_logits: torch.Tensor,
+                       tmp_out: torch.Tensor, query: torch.Tensor, key_cache: torch.Tensor,
+                       value_cache: torch.Tensor, num_kv_heads: int, scale: float,
+                       block_tables: torch.Tensor, context_lens: torch.Tensor, block_size: int,
+                       max_context_len: int, alibi_slopes: Optional[torch.Tensor],
+                       kv_cache_dtype: str) -> None:
+    """``ops.paged_attention_v2`` (csrc/attention/attention_kernels.cu:901-940)."""
+    alibi_slopes = _pa_common(query, key_cache, value_cache, block_tables, context_lens, alibi_slopes)
+    act = _act_dtype(query)
+    cache = _cache_dtype(kv_cache_dtype, act)
+    num_seqs, num_heads, head_size = query.shape
+    with torch.cuda.device(query.device):
+        _check(load_library().sw_paged_attention_v2(
+            out.data_ptr(), exp_sums.data_ptr(), max_logits.data_ptr(), tmp_out.data_ptr(),
+            query.data_ptr(), key_cache.data_ptr(), value_cache.data_ptr(), num_seqs, num_heads,
+            num_kv_heads, head_size, float(scale), block_tables.data_ptr(), context_lens.data_ptr(),
+            block_size, int(max_context_len), block_tables.stride(0),
+            alibi_slopes.data_ptr() if alibi_slopes is not None else None, query.stride(0),
+            key_cache.stride(0), key_cache.stride(1), act, cache, _stream(query)))
+
+
+# ------------------------------------------------------------------- cuda_utils
+def get_max_shared_memory_per_block_device_attribute(gpu: int) -> int:
+    """``cuda_utils.get_max_shared_memory_per_block_device_attribute``
+    (csrc/cuda_utils_kernels.cu:16-35)."""
+    out = ctypes.c_int(0)
+    _check(load_library().sw_get_max_shared_memory_per_block(int(gpu), ctypes.byref(out)))
+    return out.value
+
+
+ops = SimpleNamespace(
+    paged_attention_v1=paged_attention_v1,
+    paged_attention_v2=paged_attention_v2,
+)
+cache_ops = SimpleNamespace(
+    reshape_and_cache=reshape_and_cache,
+    copy_blocks=copy_blocks,
+    swap_blocks=swap_blocks,
+    convert_fp8_e5m2=convert_fp8_e5m2,
+)
+cuda_utils = SimpleNamespace(
+    get_max_shared_memory_per_block_device_attribute=get_max_shared_memory_per_block_device_attribute,
+)
