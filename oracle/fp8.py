@@ -30,7 +30,8 @@ def f32_to_e5m2(f: np.ndarray) -> np.ndarray:
     rn = (t + 0xFFFFF + ((t >> 21) & 1)) >> 21
     rn = np.where(rn >= 0x7C, 0x7B, rn)
     # subnormal e5m2 results: multiples of 2^-16, round half to even
-    rs = np.rint(a.view(np.float32).astype(np.float64) * 65536.0).astype(np.int64)
+    with np.errstate(invalid="ignore"):                       # NaN lanes are overwritten below
+        rs = np.rint(np.minimum(a, 0x38800000).view(np.float32).astype(np.float64) * 65536.0).astype(np.int64)
     r = np.where(a >= 0x38800000, rn, rs)
     r = np.where(a > 0x7F800000, 0x7F, r)
     return (sign | r.astype(np.uint32)).astype(np.uint8)
