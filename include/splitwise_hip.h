@@ -125,6 +125,26 @@ int sw_paged_attention_v2(void* out, float* exp_sums, float* max_logits,
                           int64_t kv_block_stride, int64_t kv_head_stride,
                           int act_dtype, int cache_dtype, void* stream);
 
+/* ---------------------------------------------------------- prefill attention
+ * Causal self-attention of a prompt run.  Replaces the prompt branch of the
+ * reference's attention backends, whose arithmetic is third-party:
+ * xformers.ops.memory_efficient_attention_forward with BlockDiagonalCausalMask
+ * (vllm/model_executor/layers/attention/backends/xformers.py:84-177) /
+ * flash_attn_func (backends/flash_attn.py:89-103); semantics = _ref_masked_attention
+ * (xformers.py:236-261).
+ *   query [T, num_heads, head_size], key/value [T, num_kv_heads, head_size], out like
+ *   query; row strides in elements.  Sequence i occupies rows
+ *   [seq_starts[i], seq_starts[i] + seq_lens[i]) (padded or packed batches alike).
+ *   alibi_slopes float [num_heads] or NULL; sliding_window <= 0 disables the window.
+ * float16 / bfloat16 only; head_size in {64,80,96,112,128,256}.              */
+int sw_prefill_attention(void* out, const void* query, const void* key,
+                         const void* value, const int32_t* seq_starts,
+                         const int32_t* seq_lens, int num_seqs, int max_seq_len,
+                         int num_heads, int num_kv_heads, int head_size,
+                         float scale, const float* alibi_slopes, int64_t q_stride,
+                         int64_t k_stride, int64_t v_stride, int64_t out_stride,
+                         int sliding_window, int act_dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,292 @@
+// Causal self-attention of a prompt run (flash-style, one pass, no score matrix in
+// memory) on gfx950 matrix cores.
+//
+// What it replaces: the prompt branch of the reference's attention backends
+// (vllm/model_executor/layers/attention/backends/xformers.py:84-177, flash_attn.py:81-114),
+// whose arithmetic lives in third-party xformers / flash-attn; the semantics are those
+// of _ref_masked_attention (xformers.py:236-261): per sequence, softmax(scale * Q K^T +
+// causal mask [+ ALiBi]) V with the probabilities rounded to the activation dtype, GQA by
+// kv_head = head / (H / KVH).  Sequences are given as (start row, length) pairs, so both
+// the reference's padded [B, max_len] batch and a packed batch are accepted.
+//
+// Tiling (wave64, v_mfma_f32_32x32x16_{bf16,f16}):
+//   * a wave owns 32 query rows of one (sequence, head); 4 independent waves per workgroup.
+//   * scores are produced TRANSPOSED, S^T = K . Q^T, so a lane holds one query column and
+//     16 keys in registers: the softmax max/sum are lane-local plus one exchange with
+//     lane^32, and the running rescale of the output needs no cross-lane traffic.
+//   * the S^T accumulator, converted to 16-bit pairs, is directly the B operand of
+//     O^T += V^T . P^T (32x32 accumulator rows are the next product's k index); the A
+//     operand V^T is read from a row-major LDS image of the V tile with the transposing
+//     ds_read_b64_tr_b16, 4 keys per read.
+//   * K fragments (8 contiguous head elements of one key per lane) come straight from
+//     global memory / L2; every LDS byte is wave-private, so there is no barrier at all.
+#include "common.cuh"
+#include <float.h>
+
+namespace sw {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+using i16x4 = __attribute__((ext_vector_type(4))) short;
+using lds_i16x4_ptr = __attribute__((address_space(3))) i16x4*;
+
+template <typename act_t> struct Mfma;
+template <> struct Mfma<bf16_t> {
+  using frag = bf16x8;
+  __device__ static __forceinline__ f32x16 run(frag a, frag b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+  __device__ static __forceinline__ __bf16 cvt(float v) { return (__bf16)v; }
+};
+template <> struct Mfma<f16_t> {
+  using frag = f16x8;
+  __device__ static __forceinline__ f32x16 run(frag a, frag b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+  }
+  __device__ static __forceinline__ _Float16 cvt(float v) { return (_Float16)v; }
+};
+
+constexpr int kPfWaves = 4;
+constexpr int kPfRows = 32;                          // query rows per wave
+constexpr int kPfKeys = 32;                          // keys per tile
+
+__host__ __device__ constexpr int pf_dp(int head) { return (head + 31) / 32 * 32; }
+__host__ __device__ constexpr int pf_vstride(int head) {          // bytes per V row in LDS
+  return (pf_dp(head) * 2 + 255) / 256 * 256 + 64;
+}
+
+template <typename act_t, int HEAD>
+__global__ void __launch_bounds__(kPfWaves * 64)
+prefill_attention_kernel(uint16_t* __restrict__ out, const uint16_t* __restrict__ q,
+                         const uint16_t* __restrict__ k, const uint16_t* __restrict__ v,
+                         const int32_t* __restrict__ seq_starts, const int32_t* __restrict__ seq_lens,
+                         int num_heads, int num_kv_heads, float scale,
+                         const float* __restrict__ alibi_slopes, int64_t q_stride, int64_t k_stride,
+                         int64_t v_stride, int64_t out_stride, int sliding_window) {
+  using M = Mfma<act_t>;
+  using frag = typename M::frag;
+  constexpr int KS = HEAD / 16;                      // k-steps of the Q.K product
+  constexpr int DP = pf_dp(HEAD);
+  constexpr int DB = DP / 32;                        // 32-row blocks of O^T
+  constexpr int VSTRIDE = pf_vstride(HEAD);
+  constexpr int CPR = HEAD / 8;                      // 16-byte chunks per V row
+  constexpr int VLOADS = kPfKeys * CPR / 64;         // V chunks per lane per tile
+  static_assert(HEAD % 16 == 0 && (kPfKeys * CPR) % 64 == 0, "unsupported head size");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  char* v_lds = smem + wave * (kPfKeys * VSTRIDE);
+
+  const int seq = blockIdx.z;
+  const int head = blockIdx.y;
+  const int seq_len = seq_lens[seq];
+  // heavy (late) query tiles first: they have the longest key loops under the causal mask
+  const int q_tile = (gridDim.x - 1 - blockIdx.x) * kPfWaves + wave;
+  const int q0 = q_tile * kPfRows;
+  if (q0 >= seq_len) return;                         // wave-uniform
+  const int64_t row0 = seq_starts[seq];
+  const int kv_head = head / (num_heads / num_kv_heads);
+  const float slope = alibi_slopes ? alibi_slopes[head] : 0.f;
+
+  const int col = lane & 31;                         // query column of S^T / O^T held by this lane
+  const int half = lane >> 5;
+  const int q_idx = q0 + col;                        // position inside the sequence
+
+  // ---- Q^T fragments (B operand, natural k order): Q[q][16*ks + 8*half + j]
+  frag qf[KS];
+  {
+    const int qr = min(q_idx, seq_len - 1);
+    const uint16_t* qp = q + (row0 + qr) * q_stride + (int64_t)head * HEAD + 8 * half;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const frag*>(qp + 16 * ks);
+  }
+
+  // zero the LDS image once: pad columns HEAD..DP-1 must read as 0 (never written again)
+  if constexpr (DP != HEAD) {
+    for (int i = lane; i < kPfKeys * VSTRIDE / 16; i += 64)
+      reinterpret_cast<uint4*>(v_lds)[i] = make_uint4(0, 0, 0, 0);
+  }
+
+  f32x16 o[DB];
+#pragma unroll
+  for (int b = 0; b < DB; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[b][r] = 0.f;
+  float m_run = -INFINITY, l_part = 0.f;
+
+  // transposing-read addressing (see header): lane 4q+p of a 16-lane group supplies row q,
+  // columns 4p..4p+3 of a 4 x 16 block; group g covers O^T rows 16*(g&1).. of key half g>>1
+  const int tr_q = (lane & 15) >> 2, tr_p = lane & 3, tr_g = lane >> 4;
+  const int tr_off = (4 * (tr_g >> 1) + tr_q) * VSTRIDE + (16 * (tr_g & 1) + 4 * tr_p) * 2;
+
+  const int k_end = min(q0 + kPfRows, seq_len);      // causal: keys < k_end
+  int k_begin = 0;
+  if (sliding_window > 0) k_begin = max(0, (q0 - sliding_window + 1) / kPfKeys * kPfKeys);
+
+  for (int k0 = k_begin; k0 < k_end; k0 += kPfKeys) {
+    // ---- V tile -> registers (issued first; written to LDS after the Q.K product)
+    uint4 vreg[VLOADS];
+#pragma unroll
+    for (int it = 0; it < VLOADS; ++it) {
+      const int c = it * 64 + lane;
+      const int key = c / CPR, ch = c - key * CPR;
+      const int kr = min(k0 + key, seq_len - 1);
+      vreg[it] = *reinterpret_cast<const uint4*>(v + (row0 + kr) * v_stride + (int64_t)kv_head * HEAD + ch * 8);
+    }
+    // ---- S^T = K . Q^T : A operand = K[key][16*ks + 8*half + j]
+    f32x16 s;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+    {
+      const int kr = min(k0 + col, seq_len - 1);
+      const uint16_t* kp = k + (row0 + kr) * k_stride + (int64_t)kv_head * HEAD + 8 * half;
+      frag kf[KS];
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) kf[ks] = *reinterpret_cast<const frag*>(kp + 16 * ks);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) s = M::run(kf[ks], qf[ks], s);
+    }
+    // ---- V registers -> row-major LDS image (wave-private)
+#pragma unroll
+    for (int it = 0; it < VLOADS; ++it) {
+      const int c = it * 64 + lane;
+      const int key = c / CPR, ch = c - key * CPR;
+      *reinterpret_cast<uint4*>(v_lds + key * VSTRIDE + ch * 16) = vreg[it];
+    }
+
+    // ---- mask, online softmax (this lane: query q_idx, keys k0 + (r&3) + 8*(r>>2) + 4*half)
+    const bool need_mask = (k0 + kPfKeys - 1 > q0) || (sliding_window > 0);
+    float m_tile = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      float x = s[r] * scale;
+      if (slope != 0.f) x += slope * (float)(key - q_idx);
+      if (need_mask) {
+        bool ok = key <= q_idx;
+        if (sliding_window > 0) ok = ok && (q_idx - key < sliding_window);
+        x = ok ? x : -INFINITY;
+      }
+      s[r] = x;
+      m_tile = fmaxf(m_tile, x);
+    }
+    m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 32, 64));
+    const float m_new = fmaxf(m_run, m_tile);
+    // a query row beyond the sequence (or a fully masked window tile) keeps m at -inf: use 0
+    const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
+    const float alpha = __expf(m_run - m_safe);
+    m_run = m_new;
+    float psum = 0.f;
+    frag pf[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float p = __expf(s[r] - m_safe);
+      const auto pr = M::cvt(p);                     // rounded to the activation dtype
+      psum += p;
+      pf[r >> 3][r & 7] = pr;
+    }
+    l_part = l_part * alpha + psum;
+#pragma unroll
+    for (int b = 0; b < DB; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[b][r] *= alpha;
+
+    // ---- O^T += V^T . P^T ; A operand element j <-> key 16*st + 8*(j>>2) + 4*half + (j&3)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+#pragma unroll
+      for (int b = 0; b < DB; ++b) {
+        const char* base = v_lds + tr_off + (16 * st) * VSTRIDE + b * 64;
+        const i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_i16x4_ptr)(base));
+        const i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_i16x4_ptr)(base + 8 * VSTRIDE));
+        union { struct { i16x4 a, b; } p; frag f; } vf;
+        vf.p.a = lo;
+        vf.p.b = hi;
+        o[b] = M::run(vf.f, pf[st], o[b]);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // the image is rewritten next tile
+  }
+
+  // ---- normalise and store: this lane holds query q_idx, O^T rows d = 32*b + (r&3) + 8*(r>>2) + 4*half
+  const float l_tot = l_part + __shfl_xor(l_part, 32, 64);
+  const float inv = 1.f / l_tot;
+  if (q_idx < seq_len) {
+    uint16_t* op = out + (row0 + q_idx) * out_stride + (int64_t)head * HEAD;
+#pragma unroll
+    for (int b = 0; b < DB; ++b) {
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const int d = 32 * b + 8 * r4 + 4 * half;
+        if (d < HEAD) {
+          uint16_t w[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) w[j] = Conv<act_t>::from_float(o[b][4 * r4 + j] * inv);
+          *reinterpret_cast<uint2*>(op + d) =
+              make_uint2((uint32_t)w[0] | ((uint32_t)w[1] << 16), (uint32_t)w[2] | ((uint32_t)w[3] << 16));
+        }
+      }
+    }
+  }
+}
+
+template <typename act_t, int HEAD>
+int launch_prefill(void* out, const void* q, const void* k, const void* v, const int32_t* seq_starts,
+                   const int32_t* seq_lens, int num_seqs, int max_seq_len, int num_heads, int num_kv_heads,
+                   float scale, const float* alibi, int64_t q_stride, int64_t k_stride, int64_t v_stride,
+                   int64_t out_stride, int sliding_window, hipStream_t stream) {
+  const int rows_per_wg = kPfWaves * kPfRows;
+  dim3 grid((max_seq_len + rows_per_wg - 1) / rows_per_wg, num_heads, num_seqs);
+  const size_t smem = (size_t)kPfWaves * kPfKeys * pf_vstride(HEAD);
+  prefill_attention_kernel<act_t, HEAD><<<grid, kPfWaves * 64, smem, stream>>>(
+      static_cast<uint16_t*>(out), static_cast<const uint16_t*>(q), static_cast<const uint16_t*>(k),
+      static_cast<const uint16_t*>(v), seq_starts, seq_lens, num_heads, num_kv_heads, scale, alibi, q_stride,
+      k_stride, v_stride, out_stride, sliding_window);
+  SW_CHECK_LAUNCH();
+  return SW_OK;
+}
+
+}  // namespace sw
+
+extern "C" int sw_prefill_attention(void* out, const void* query, const void* key, const void* value,
+                                    const int32_t* seq_starts, const int32_t* seq_lens, int num_seqs,
+                                    int max_seq_len, int num_heads, int num_kv_heads, int head_size,
+                                    float scale, const float* alibi_slopes, int64_t q_stride,
+                                    int64_t k_stride, int64_t v_stride, int64_t out_stride,
+                                    int sliding_window, int act_dtype, void* stream) {
+  using namespace sw;
+  if (num_seqs == 0 || max_seq_len == 0) return SW_OK;
+  SW_CHECK_ARG(num_seqs > 0 && max_seq_len > 0 && num_heads > 0 && num_kv_heads > 0 &&
+                   num_heads % num_kv_heads == 0, "prefill_attention: bad shape");
+  SW_CHECK_ARG(act_dtype == SW_F16 || act_dtype == SW_BF16,
+               "Unsupported data type for prefill attention: %d (float16 / bfloat16 only)", act_dtype);
+  SW_CHECK_ARG(num_seqs <= 65535 && num_heads <= 65535, "prefill_attention: grid too large");
+  SW_CHECK_ARG(q_stride % 8 == 0 && k_stride % 8 == 0 && v_stride % 8 == 0 && out_stride % 4 == 0 &&
+                   reinterpret_cast<uintptr_t>(query) % 16 == 0 && reinterpret_cast<uintptr_t>(key) % 16 == 0 &&
+                   reinterpret_cast<uintptr_t>(value) % 16 == 0 && reinterpret_cast<uintptr_t>(out) % 8 == 0,
+               "prefill_attention: rows must be 16-byte aligned");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+#define SW_PF(HEAD)                                                                                       \
+  return act_dtype == SW_BF16                                                                             \
+             ? launch_prefill<bf16_t, HEAD>(out, query, key, value, seq_starts, seq_lens, num_seqs,       \
+                                            max_seq_len, num_heads, num_kv_heads, scale, alibi_slopes,    \
+                                            q_stride, k_stride, v_stride, out_stride, sliding_window, s)  \
+             : launch_prefill<f16_t, HEAD>(out, query, key, value, seq_starts, seq_lens, num_seqs,        \
+                                           max_seq_len, num_heads, num_kv_heads, scale, alibi_slopes,     \
+                                           q_stride, k_stride, v_stride, out_stride, sliding_window, s)
+  switch (head_size) {
+    case 64: SW_PF(64);
+    case 80: SW_PF(80);
+    case 96: SW_PF(96);
+    case 112: SW_PF(112);
+    case 128: SW_PF(128);
+    case 256: SW_PF(256);
+    default: break;
+  }
+#undef SW_PF
+  set_error("Unsupported head size: %d", head_size);
+  return SW_ERR_INVALID;
+}

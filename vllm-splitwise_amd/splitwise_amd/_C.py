@@ -46,6 +46,9 @@ _SIGNATURES = {
                               _c_int, _c_int, _c_int, _c_int, _c_float, _c_void_p, _c_void_p, _c_int,
                               _c_int, _c_int, _c_void_p, _c_i64, _c_i64, _c_i64, _c_int, _c_int,
                               _c_void_p],
+    "sw_prefill_attention": [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int,
+                             _c_int, _c_int, _c_int, _c_float, _c_void_p, _c_i64, _c_i64, _c_i64, _c_i64,
+                             _c_int, _c_int, _c_void_p],
 }
 
 _lib = None
@@ -263,6 +266,29 @@ def paged_attention_v2(out: torch.Tensor, exp_sums: torch.Tensor, max_logits: to
             key_cache.stride(0), key_cache.stride(1), act, cache, _stream(query)))
 
 
+def prefill_attention(out: torch.Tensor, query: torch.Tensor, key: torch.Tensor, value: torch.Tensor,
+                      seq_starts: torch.Tensor, seq_lens: torch.Tensor, max_seq_len: int, scale: float,
+                      alibi_slopes: Optional[torch.Tensor] = None, sliding_window: Optional[int] = None) -> None:
+    """Causal prompt attention over (start, length) sequences; stands where the reference calls
+    xformers / flash-attn (backends/xformers.py:155-164).  query [T, H, D], key/value [T, KVH, D]."""
+    _require_cuda(out, query, key, value, seq_starts, seq_lens)
+    if seq_starts.dtype != torch.int32 or seq_lens.dtype != torch.int32:
+        raise RuntimeError("prefill_attention: seq_starts and seq_lens must be int32")
+    for t in (out, query, key, value):
+        if t.stride(2) != 1 or t.stride(1) != t.shape[2]:
+            raise RuntimeError("prefill_attention: heads must be contiguous")
+    act = _act_dtype(query)
+    if alibi_slopes is not None and not alibi_slopes.is_cuda:
+        alibi_slopes = alibi_slopes.to(query.device)
+    with torch.cuda.device(query.device):
+        _check(load_library().sw_prefill_attention(
+            out.data_ptr(), query.data_ptr(), key.data_ptr(), value.data_ptr(), seq_starts.data_ptr(),
+            seq_lens.data_ptr(), seq_lens.numel(), int(max_seq_len), query.shape[1], key.shape[1],
+            query.shape[2], float(scale), alibi_slopes.data_ptr() if alibi_slopes is not None else None,
+            query.stride(0), key.stride(0), value.stride(0), out.stride(0),
+            int(sliding_window) if sliding_window else 0, act, _stream(query)))
+
+
 # ------------------------------------------------------------------- cuda_utils
 def get_max_shared_memory_per_block_device_attribute(gpu: int) -> int:
     """``cuda_utils.get_max_shared_memory_per_block_device_attribute``
@@ -275,6 +301,7 @@ def get_max_shared_memory_per_block_device_attribute(gpu: int) -> int:
 ops = SimpleNamespace(
     paged_attention_v1=paged_attention_v1,
     paged_attention_v2=paged_attention_v2,
+    prefill_attention=prefill_attention,
 )
 cache_ops = SimpleNamespace(
     reshape_and_cache=reshape_and_cache,

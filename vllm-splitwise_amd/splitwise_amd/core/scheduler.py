@@ -1,0 +1,360 @@
+"""Iteration-level scheduler with Splitwise block tracking.
+
+Decisions restated from vllm/core/scheduler.py:173-432: each step is either a PROMPT
+run (admit waiting requests in arrival order while blocks, the token budget, the
+sequence budget and the padding budget allow) or, if nothing could be admitted, a
+DECODE run over everything running (preempting the youngest requests when blocks run
+out, swapping requests back in when they fit).  With ``track_prompt_blocks`` every
+sequence that has produced at most one token contributes its block table to
+``blocks_to_nw[slot]`` (:269-277, :376-385), coalesced into (start, length) runs: the
+prompt pool pushes these blocks, the token pool waits for them.
+
+``schedule()`` reproduces the reference's serial alternation.  ``schedule_prompts()``
+and ``schedule_decodes()`` expose the two halves separately so that a split
+deployment can keep a prompt step and a decode step in flight at the same time
+(the reference never overlaps the pools: vllm/executor/ray_gpu_executor.py:292-293).
+"""
+import enum
+import time
+from collections import defaultdict, deque
+from typing import Deque, Dict, Iterable, List, Optional, Set, Tuple, Union
+
+from ..config import CacheConfig, SchedulerConfig
+from ..sequence import (Sequence, SequenceData, SequenceGroup, SequenceGroupMetadata, SequenceStatus)
+from ..utils import SeqToSlotMapper, coalesce_blocks_by_id
+from .block_manager import AllocStatus, BlockSpaceManager
+
+
+class PreemptionMode(enum.Enum):
+    SWAP = enum.auto()
+    RECOMPUTE = enum.auto()
+
+
+class SchedulerOutputs:
+    """vllm/core/scheduler.py:32-80."""
+
+    def __init__(self, scheduled_seq_groups: Iterable[SequenceGroup], prompt_run: bool, num_batched_tokens: int,
+                 blocks_to_swap_in: Dict[int, int], blocks_to_swap_out: Dict[int, int],
+                 blocks_to_copy: Dict[int, List[int]], blocks_to_nw: Dict[int, List[Tuple[int, int]]],
+                 ignored_seq_groups: List[SequenceGroup]) -> None:
+        self.scheduled_seq_groups = scheduled_seq_groups
+        self.prompt_run = prompt_run
+        self.num_batched_tokens = num_batched_tokens
+        self.blocks_to_swap_in = blocks_to_swap_in
+        self.blocks_to_swap_out = blocks_to_swap_out
+        self.blocks_to_copy = blocks_to_copy
+        self.blocks_to_nw = blocks_to_nw
+        assert not (blocks_to_swap_in and blocks_to_swap_out)
+        self.ignored_seq_groups = ignored_seq_groups
+
+    def is_empty(self) -> bool:
+        return (not self.scheduled_seq_groups and not self.blocks_to_swap_in and not self.blocks_to_swap_out
+                and not self.blocks_to_copy and not self.blocks_to_nw)
+
+
+def _fcfs_order(now: float, groups: Iterable[SequenceGroup]) -> Deque[SequenceGroup]:
+    """Oldest arrival first; the sort is stable (vllm/core/policy.py:16-36)."""
+    return deque(sorted(groups, key=lambda g: now - g.metrics.arrival_time, reverse=True))
+
+
+class Scheduler:
+    def __init__(self, scheduler_config: SchedulerConfig, cache_config: CacheConfig, lora_config=None,
+                 track_prompt_blocks: bool = False, strict_reference: bool = False) -> None:
+        """``strict_reference`` reproduces two behaviours of the reference that the default mode
+        repairs: (1) a sequence re-admitted after preemption-by-recompute draws a NEW hand-off
+        slot and its old one is never returned (vllm/core/scheduler.py:446-451 calls set_seq
+        again; :496-507 frees only the blocks); (2) such a sequence is re-prefilled but, having
+        more than one output token, is left out of blocks_to_nw (:273, :381), so the token pool
+        would decode from stale KV.  By default the slot is kept and the re-prefilled blocks
+        are pushed again."""
+        if lora_config is not None:
+            raise NotImplementedError("LoRA is outside the scope of this build")
+        self.scheduler_config = scheduler_config
+        self.cache_config = cache_config
+        self.track_prompt_blocks = track_prompt_blocks
+        self.strict_reference = strict_reference
+        # steps for which a sequence's blocks are still announced in blocks_to_nw:
+        # 2 after every (re-)prefill = the prompt step and the first decode step
+        self._kv_pending: Dict[int, int] = {}
+        self.seq_to_slot_mapper: Optional[SeqToSlotMapper] = SeqToSlotMapper() if track_prompt_blocks else None
+        self.prompt_limit = min(scheduler_config.max_model_len, scheduler_config.max_num_batched_tokens)
+        self.block_manager = BlockSpaceManager(
+            block_size=cache_config.block_size, num_gpu_blocks=cache_config.num_gpu_blocks,
+            num_cpu_blocks=cache_config.num_cpu_blocks, sliding_window=cache_config.sliding_window,
+            enable_caching=cache_config.enable_prefix_caching)
+        self.waiting: Deque[SequenceGroup] = deque()
+        self.running: Deque[SequenceGroup] = deque()
+        self.swapped: Deque[SequenceGroup] = deque()
+        # split mode only: groups whose prompt step is still executing on the prompt pool
+        self.prefilling: Set[str] = set()
+
+    # -------------------------------------------------------------- queue admin
+    def add_seq_group(self, seq_group: SequenceGroup) -> None:
+        self.waiting.append(seq_group)
+
+    def abort_seq_group(self, request_id: Union[str, Iterable[str]]) -> None:
+        ids = {request_id} if isinstance(request_id, str) else set(request_id)
+        for queue in (self.waiting, self.running, self.swapped):
+            hit = [g for g in queue if g.request_id in ids]
+            for group in hit:
+                ids.discard(group.request_id)
+                queue.remove(group)
+                self.prefilling.discard(group.request_id)
+                for seq in group.get_seqs():
+                    if not seq.is_finished():
+                        seq.status = SequenceStatus.FINISHED_ABORTED
+                        self.free_seq(seq)
+
+    def has_unfinished_seqs(self) -> bool:
+        return bool(self.waiting or self.running or self.swapped)
+
+    def get_num_unfinished_seq_groups(self) -> int:
+        return len(self.waiting) + len(self.running) + len(self.swapped)
+
+    # ------------------------------------------------------------ prompt half
+    def _note_blocks_to_nw(self, seq: Sequence, blocks_to_nw: Dict[int, List[int]]) -> None:
+        if self.strict_reference:
+            due = seq.get_output_len() <= 1
+        else:
+            left = self._kv_pending.get(seq.seq_id, 0)
+            due = left > 0
+            if due:
+                self._kv_pending[seq.seq_id] = left - 1
+        if due:
+            slot = self.seq_to_slot_mapper.get_slot_id(seq.seq_id)
+            blocks_to_nw[slot].extend(self.block_manager.get_block_table(seq))
+
+    def _admit_prompts(self, blocks_to_nw: Dict[int, List[int]]):
+        """-> (scheduled groups, ignored groups, padded token count)."""
+        cfg = self.scheduler_config
+        scheduled: List[SequenceGroup] = []
+        ignored: List[SequenceGroup] = []
+        num_curr_seqs = sum(g.get_max_num_running_seqs() for g in self.running)
+        num_prompts, longest = 0, 0
+        total_len = 0
+        while self.waiting:
+            group = self.waiting[0]
+            waiting_seqs = group.get_seqs(status=SequenceStatus.WAITING)
+            assert len(waiting_seqs) == 1, "Waiting sequence group should have only one prompt sequence."
+            prompt_len = waiting_seqs[0].get_len()
+            too_long = prompt_len > self.prompt_limit
+            if not too_long:
+                verdict = self.block_manager.can_allocate(group)
+                if verdict == AllocStatus.LATER:
+                    break
+                too_long = verdict == AllocStatus.NEVER
+            if too_long:
+                for seq in waiting_seqs:
+                    seq.status = SequenceStatus.FINISHED_IGNORED
+                ignored.append(group)
+                self.waiting.popleft()
+                continue
+            # the batch is padded to its longest prompt: budget the padded size
+            padded = (num_prompts + 1) * max(longest, prompt_len)
+            if padded > cfg.max_num_batched_tokens:
+                break
+            new_seqs = group.get_max_num_running_seqs()
+            if num_curr_seqs + new_seqs > cfg.max_num_seqs:
+                break
+            if padded - (total_len + prompt_len) > cfg.max_paddings:
+                break
+            num_prompts += 1
+            longest = max(longest, prompt_len)
+            total_len += prompt_len
+            self.waiting.popleft()
+            self._allocate(group)
+            self.running.append(group)
+            num_curr_seqs += new_seqs
+            scheduled.append(group)
+            if self.track_prompt_blocks:
+                for seq in group.get_seqs():
+                    self._note_blocks_to_nw(seq, blocks_to_nw)
+        return scheduled, ignored, num_prompts * longest
+
+    # ------------------------------------------------------------ decode half
+    def _reserve_decode_slots(self, now: float, blocks_to_swap_in, blocks_to_swap_out, blocks_to_copy,
+                              skip: Optional[Set[str]] = None) -> None:
+        """Gives every running group one more token slot, preempting from the back of the
+        FCFS order when blocks run out; then swaps groups back in while they fit."""
+        self.running = _fcfs_order(now, self.running)
+        kept: Deque[SequenceGroup] = deque()
+        preempted: List[SequenceGroup] = []
+        while self.running:
+            group = self.running.popleft()
+            if skip and group.request_id in skip:
+                kept.append(group)               # its prompt step is still in flight: no new slot yet
+                continue
+            while not self.block_manager.can_append_slot(group):
+                victim = None
+                for cand in reversed(self.running):
+                    if not (skip and cand.request_id in skip):
+                        victim = cand
+                        break
+                if victim is not None:
+                    self.running.remove(victim)
+                    self._preempt(victim, blocks_to_swap_out)
+                    preempted.append(victim)
+                else:
+                    self._preempt(group, blocks_to_swap_out)
+                    preempted.append(group)
+                    break
+            else:
+                self._append_slot(group, blocks_to_copy)
+                kept.append(group)
+        self.running = kept
+
+        self.swapped = _fcfs_order(now, self.swapped)
+        if not preempted:
+            num_curr_seqs = sum(g.get_max_num_running_seqs() for g in self.running)
+            while self.swapped:
+                group = self.swapped[0]
+                if not self.block_manager.can_swap_in(group):
+                    break
+                new_seqs = group.get_max_num_running_seqs()
+                if num_curr_seqs + new_seqs > self.scheduler_config.max_num_seqs:
+                    break
+                self.swapped.popleft()
+                self._swap_in(group, blocks_to_swap_in)
+                self._append_slot(group, blocks_to_copy)
+                num_curr_seqs += new_seqs
+                self.running.append(group)
+
+    # --------------------------------------------------------------- schedule
+    def _schedule(self) -> SchedulerOutputs:
+        blocks_to_swap_in: Dict[int, int] = {}
+        blocks_to_swap_out: Dict[int, int] = {}
+        blocks_to_copy: Dict[int, List[int]] = {}
+        blocks_to_nw: Dict[int, List[int]] = defaultdict(list)
+        now = time.monotonic()
+
+        if not self.swapped:
+            scheduled, ignored, padded_tokens = self._admit_prompts(blocks_to_nw)
+            if scheduled or ignored:
+                return SchedulerOutputs(scheduled, True, padded_tokens, blocks_to_swap_in, blocks_to_swap_out,
+                                        blocks_to_copy, coalesce_blocks_by_id(blocks_to_nw), ignored)
+
+        self._reserve_decode_slots(now, blocks_to_swap_in, blocks_to_swap_out, blocks_to_copy)
+        num_batched_tokens = sum(g.num_seqs(status=SequenceStatus.RUNNING) for g in self.running)
+        if self.track_prompt_blocks:
+            for group in self.running:
+                for seq in group.get_seqs(status=SequenceStatus.RUNNING):
+                    self._note_blocks_to_nw(seq, blocks_to_nw)
+        return SchedulerOutputs(self.running, False, num_batched_tokens, blocks_to_swap_in, blocks_to_swap_out,
+                                blocks_to_copy, coalesce_blocks_by_id(blocks_to_nw), [])
+
+    def _metadata(self, outputs: SchedulerOutputs, groups: Iterable[SequenceGroup]) -> List[SequenceGroupMetadata]:
+        now = time.time()
+        metas: List[SequenceGroupMetadata] = []
+        for group in groups:
+            group.maybe_set_first_scheduled_time(now)
+            seq_data: Dict[int, SequenceData] = {}
+            block_tables: Dict[int, List[int]] = {}
+            for seq in group.get_seqs(status=SequenceStatus.RUNNING):
+                seq_data[seq.seq_id] = seq.data
+                block_tables[seq.seq_id] = self.block_manager.get_block_table(seq)
+            metas.append(SequenceGroupMetadata(
+                request_id=group.request_id, is_prompt=outputs.prompt_run, seq_data=seq_data,
+                sampling_params=group.sampling_params, block_tables=block_tables,
+                computed_block_nums=[], state=group.state))
+        return metas
+
+    def schedule(self) -> Tuple[List[SequenceGroupMetadata], SchedulerOutputs]:
+        outputs = self._schedule()
+        return self._metadata(outputs, outputs.scheduled_seq_groups), outputs
+
+    # ------------------------------------------------------------- split mode
+    def schedule_prompts(self) -> Tuple[List[SequenceGroupMetadata], SchedulerOutputs]:
+        """One prompt step for the prompt pool; admitted groups join ``running`` but are held out
+        of decode steps until ``prompt_step_done`` reports their first token."""
+        blocks_to_nw: Dict[int, List[int]] = defaultdict(list)
+        scheduled, ignored = [], []
+        padded = 0
+        if not self.swapped:
+            scheduled, ignored, padded = self._admit_prompts(blocks_to_nw)
+        for group in scheduled:
+            self.prefilling.add(group.request_id)
+        outputs = SchedulerOutputs(scheduled, True, padded, {}, {}, {}, coalesce_blocks_by_id(blocks_to_nw),
+                                   ignored)
+        return self._metadata(outputs, scheduled), outputs
+
+    def prompt_step_done(self, request_ids: Iterable[str]) -> None:
+        for rid in request_ids:
+            self.prefilling.discard(rid)
+
+    def schedule_decodes(self) -> Tuple[List[SequenceGroupMetadata], SchedulerOutputs]:
+        """One decode step for the token pool over the running groups whose prompt has finished."""
+        blocks_to_swap_in: Dict[int, int] = {}
+        blocks_to_swap_out: Dict[int, int] = {}
+        blocks_to_copy: Dict[int, List[int]] = {}
+        blocks_to_nw: Dict[int, List[int]] = defaultdict(list)
+        self._reserve_decode_slots(time.monotonic(), blocks_to_swap_in, blocks_to_swap_out, blocks_to_copy,
+                                   skip=self.prefilling)
+        ready = [g for g in self.running if g.request_id not in self.prefilling]
+        if self.track_prompt_blocks:
+            for group in ready:
+                for seq in group.get_seqs(status=SequenceStatus.RUNNING):
+                    self._note_blocks_to_nw(seq, blocks_to_nw)
+        tokens = sum(g.num_seqs(status=SequenceStatus.RUNNING) for g in ready)
+        outputs = SchedulerOutputs(ready, False, tokens, blocks_to_swap_in, blocks_to_swap_out, blocks_to_copy,
+                                   coalesce_blocks_by_id(blocks_to_nw), [])
+        return self._metadata(outputs, ready), outputs
+
+    # -------------------------------------------------------------- bookkeeping
+    def fork_seq(self, parent_seq: Sequence, child_seq: Sequence) -> None:
+        self.block_manager.fork(parent_seq, child_seq)
+
+    def free_seq(self, seq: Sequence) -> None:
+        self.block_manager.free(seq)
+        if self.seq_to_slot_mapper is not None and seq.seq_id in self.seq_to_slot_mapper:
+            self.seq_to_slot_mapper.free_seq(seq.seq_id)
+        self._kv_pending.pop(seq.seq_id, None)
+
+    def free_finished_seq_groups(self) -> None:
+        self.running = deque(g for g in self.running if not g.is_finished())
+
+    def mark_blocks_as_computed(self, seq_group: SequenceGroup) -> None:
+        self.block_manager.mark_blocks_as_computed(seq_group)
+
+    def _allocate(self, seq_group: SequenceGroup) -> None:
+        self.block_manager.allocate(seq_group)
+        for seq in seq_group.get_seqs(status=SequenceStatus.WAITING):
+            seq.status = SequenceStatus.RUNNING
+            if self.seq_to_slot_mapper is not None:
+                if self.strict_reference or seq.seq_id not in self.seq_to_slot_mapper:
+                    self.seq_to_slot_mapper.set_seq(seq.seq_id)
+                self._kv_pending[seq.seq_id] = 2
+
+    def _append_slot(self, seq_group: SequenceGroup, blocks_to_copy: Dict[int, List[int]]) -> None:
+        for seq in seq_group.get_seqs(status=SequenceStatus.RUNNING):
+            cow = self.block_manager.append_slot(seq)
+            if cow is not None:
+                src, dst = cow
+                blocks_to_copy.setdefault(src, []).append(dst)
+
+    def _preempt(self, seq_group: SequenceGroup, blocks_to_swap_out: Dict[int, int],
+                 preemption_mode: Optional[PreemptionMode] = None) -> None:
+        # a lone sequence is recomputed (cheaper); groups with several sequences are swapped out
+        # (vllm/core/scheduler.py:467-494)
+        if preemption_mode is None:
+            preemption_mode = (PreemptionMode.RECOMPUTE if seq_group.get_max_num_running_seqs() == 1
+                               else PreemptionMode.SWAP)
+        if preemption_mode == PreemptionMode.RECOMPUTE:
+            seqs = seq_group.get_seqs(status=SequenceStatus.RUNNING)
+            assert len(seqs) == 1
+            for seq in seqs:
+                seq.status = SequenceStatus.WAITING
+                self.block_manager.free(seq)
+            self.waiting.appendleft(seq_group)
+        else:
+            if not self.block_manager.can_swap_out(seq_group):
+                raise RuntimeError("Aborted due to the lack of CPU swap space. Please increase the swap space "
+                                   "to avoid this error.")
+            blocks_to_swap_out.update(self.block_manager.swap_out(seq_group))
+            for seq in seq_group.get_seqs(status=SequenceStatus.RUNNING):
+                seq.status = SequenceStatus.SWAPPED
+            self.swapped.append(seq_group)
+
+    def _swap_in(self, seq_group: SequenceGroup, blocks_to_swap_in: Dict[int, int]) -> None:
+        blocks_to_swap_in.update(self.block_manager.swap_in(seq_group))
+        for seq in seq_group.get_seqs(status=SequenceStatus.SWAPPED):
+            seq.status = SequenceStatus.RUNNING
