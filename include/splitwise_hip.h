@@ -145,6 +145,34 @@ int sw_prefill_attention(void* out, const void* query, const void* key,
                          int64_t k_stride, int64_t v_stride, int64_t out_stride,
                          int sliding_window, int act_dtype, void* stream);
 
+/* -------------------------------------------- row-wise operators beside the path
+ * csrc/layernorm_kernels.cu:70-118 rms_norm / fused_add_rms_norm.
+ *   out = (act)(x * rsqrt(mean(x^2) + eps)) * weight, per row of hidden_size elements.
+ *   fused: residual := input + residual (stored), input := norm(residual) * weight.
+ *   input rows may be strided (input_stride elements); out / residual are contiguous. */
+int sw_rms_norm(void* out, const void* input, const void* weight, float epsilon,
+                int64_t num_tokens, int hidden_size, int64_t input_stride,
+                int act_dtype, void* stream);
+int sw_fused_add_rms_norm(void* input, void* residual, const void* weight,
+                          float epsilon, int64_t num_tokens, int hidden_size,
+                          int64_t input_stride, int act_dtype, void* stream);
+
+/* csrc/pos_encoding_kernels.cu:120-171 rotary_embedding, in place on query and key.
+ *   positions int64 [num_tokens]; cos_sin_cache act_dtype [max_position, rot_dim]
+ *   (cos in the first half of a row, sin in the second); is_neox selects the
+ *   (i, i + rot_dim/2) pairing, otherwise (2i, 2i+1).  Products are formed in fp32
+ *   and rounded once (the reference rounds each half-precision operation).   */
+int sw_rotary_embedding(const int64_t* positions, void* query, void* key,
+                        int64_t num_tokens, int num_heads, int num_kv_heads,
+                        int head_size, const void* cos_sin_cache, int rot_dim,
+                        int is_neox, int64_t query_stride, int64_t key_stride,
+                        int act_dtype, void* stream);
+
+/* csrc/activation_kernels.cu:66-84 silu_and_mul: out[t, i] = silu(in[t, i]) * in[t, d + i],
+ * input [num_tokens, 2 * d] with row stride input_stride, out [num_tokens, d].       */
+int sw_silu_and_mul(void* out, const void* input, int64_t num_tokens, int d,
+                    int64_t input_stride, int act_dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

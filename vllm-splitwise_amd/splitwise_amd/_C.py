@@ -49,6 +49,12 @@ _SIGNATURES = {
     "sw_prefill_attention": [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int,
                              _c_int, _c_int, _c_int, _c_float, _c_void_p, _c_i64, _c_i64, _c_i64, _c_i64,
                              _c_int, _c_int, _c_void_p],
+    "sw_rms_norm": [_c_void_p, _c_void_p, _c_void_p, _c_float, _c_i64, _c_int, _c_i64, _c_int, _c_void_p],
+    "sw_fused_add_rms_norm": [_c_void_p, _c_void_p, _c_void_p, _c_float, _c_i64, _c_int, _c_i64, _c_int,
+                              _c_void_p],
+    "sw_rotary_embedding": [_c_void_p, _c_void_p, _c_void_p, _c_i64, _c_int, _c_int, _c_int, _c_void_p, _c_int,
+                            _c_int, _c_i64, _c_i64, _c_int, _c_void_p],
+    "sw_silu_and_mul": [_c_void_p, _c_void_p, _c_i64, _c_int, _c_i64, _c_int, _c_void_p],
 }
 
 _lib = None
@@ -289,6 +295,78 @@ def prefill_attention(out: torch.Tensor, query: torch.Tensor, key: torch.Tensor,
             int(sliding_window) if sliding_window else 0, act, _stream(query)))
 
 
+def _rows(t: torch.Tensor):
+    """(number of rows, row stride in elements) of a tensor whose last dim is contiguous and whose
+    leading dims collapse to one stride."""
+    if t.stride(-1) != 1:
+        raise RuntimeError("last dimension must be contiguous")
+    width = t.shape[-1]
+    rows = t.numel() // max(width, 1)
+    if t.dim() == 1:
+        return 1, width
+    stride = t.stride(-2)
+    expect = stride
+    for d in range(t.dim() - 3, -1, -1):
+        expect *= t.shape[d + 1]
+        if t.shape[d] != 1 and t.stride(d) != expect:
+            raise RuntimeError("leading dimensions must collapse to a single row stride")
+    return rows, stride
+
+
+def rms_norm(out: torch.Tensor, input: torch.Tensor, weight: torch.Tensor, epsilon: float) -> None:
+    """``ops.rms_norm`` (csrc/layernorm_kernels.cu:70-92)."""
+    _require_cuda(out, input, weight)
+    rows, stride = _rows(input)
+    if not out.is_contiguous():
+        raise RuntimeError("rms_norm: out must be contiguous")
+    with torch.cuda.device(input.device):
+        _check(load_library().sw_rms_norm(out.data_ptr(), input.data_ptr(), weight.data_ptr(), float(epsilon),
+                                          rows, input.shape[-1], stride, _act_dtype(input), _stream(input)))
+
+
+def fused_add_rms_norm(input: torch.Tensor, residual: torch.Tensor, weight: torch.Tensor,
+                       epsilon: float) -> None:
+    """``ops.fused_add_rms_norm`` (csrc/layernorm_kernels.cu:94-118), in place on both."""
+    _require_cuda(input, residual, weight)
+    rows, stride = _rows(input)
+    if not residual.is_contiguous():
+        raise RuntimeError("fused_add_rms_norm: residual must be contiguous")
+    with torch.cuda.device(input.device):
+        _check(load_library().sw_fused_add_rms_norm(input.data_ptr(), residual.data_ptr(), weight.data_ptr(),
+                                                    float(epsilon), rows, input.shape[-1], stride,
+                                                    _act_dtype(input), _stream(input)))
+
+
+def rotary_embedding(positions: torch.Tensor, query: torch.Tensor, key: torch.Tensor, head_size: int,
+                     cos_sin_cache: torch.Tensor, is_neox: bool) -> None:
+    """``ops.rotary_embedding`` (csrc/pos_encoding_kernels.cu:120-171), in place on query / key."""
+    _require_cuda(positions, query, key, cos_sin_cache)
+    if positions.dtype != torch.int64 or not positions.is_contiguous():
+        raise RuntimeError("rotary_embedding: positions must be contiguous int64")
+    if cos_sin_cache.dtype != query.dtype:
+        raise RuntimeError("rotary_embedding: cos_sin_cache must have the dtype of query")
+    q_rows, q_stride = _rows(query)
+    k_rows, k_stride = _rows(key)
+    if q_rows != positions.numel() or k_rows != q_rows:
+        raise RuntimeError("rotary_embedding: positions / query / key disagree on the token count")
+    with torch.cuda.device(query.device):
+        _check(load_library().sw_rotary_embedding(
+            positions.data_ptr(), query.data_ptr(), key.data_ptr(), q_rows, query.shape[-1] // head_size,
+            key.shape[-1] // head_size, head_size, cos_sin_cache.data_ptr(), cos_sin_cache.shape[1],
+            1 if is_neox else 0, q_stride, k_stride, _act_dtype(query), _stream(query)))
+
+
+def silu_and_mul(out: torch.Tensor, input: torch.Tensor) -> None:
+    """``ops.silu_and_mul`` (csrc/activation_kernels.cu:66-84)."""
+    _require_cuda(out, input)
+    rows, stride = _rows(input)
+    if not out.is_contiguous():
+        raise RuntimeError("silu_and_mul: out must be contiguous")
+    with torch.cuda.device(input.device):
+        _check(load_library().sw_silu_and_mul(out.data_ptr(), input.data_ptr(), rows, input.shape[-1] // 2,
+                                              stride, _act_dtype(input), _stream(input)))
+
+
 # ------------------------------------------------------------------- cuda_utils
 def get_max_shared_memory_per_block_device_attribute(gpu: int) -> int:
     """``cuda_utils.get_max_shared_memory_per_block_device_attribute``
@@ -302,6 +380,10 @@ ops = SimpleNamespace(
     paged_attention_v1=paged_attention_v1,
     paged_attention_v2=paged_attention_v2,
     prefill_attention=prefill_attention,
+    rms_norm=rms_norm,
+    fused_add_rms_norm=fused_add_rms_norm,
+    rotary_embedding=rotary_embedding,
+    silu_and_mul=silu_and_mul,
 )
 cache_ops = SimpleNamespace(
     reshape_and_cache=reshape_and_cache,

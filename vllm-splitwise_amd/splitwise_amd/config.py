@@ -141,8 +141,6 @@ class CacheConfig:
             raise ValueError(f"GPU memory utilization must be less than 1.0. Got {gpu_memory_utilization}.")
         if cache_dtype not in ("auto", "fp8_e5m2"):
             raise ValueError(f"Unknown kv cache dtype: {cache_dtype}")
-        if block_size not in (8, 16, 32):
-            raise ValueError(f"block_size must be 8, 16 or 32, got {block_size}")
         if enable_prefix_caching:
             raise NotImplementedError("prefix caching is not built yet")
         self.num_gpu_blocks: Optional[int] = None

@@ -37,7 +37,10 @@ class SchedulerOutputs:
                  blocks_to_swap_in: Dict[int, int], blocks_to_swap_out: Dict[int, int],
                  blocks_to_copy: Dict[int, List[int]], blocks_to_nw: Dict[int, List[Tuple[int, int]]],
                  ignored_seq_groups: List[SequenceGroup]) -> None:
-        self.scheduled_seq_groups = scheduled_seq_groups
+        # The reference orders every non-empty batch by (lora id, request id): its set of LoRA
+        # requests is {None}, which has length 1, so _sort_by_lora_ids always runs
+        # (vllm/core/scheduler.py:56-73).  Request ids compare as strings ('10' < '9').
+        self.scheduled_seq_groups = sorted(scheduled_seq_groups, key=lambda g: g.request_id)
         self.prompt_run = prompt_run
         self.num_batched_tokens = num_batched_tokens
         self.blocks_to_swap_in = blocks_to_swap_in

@@ -1,0 +1,143 @@
+"""The synchronous engine: request intake, one scheduler + executor step, output processing.
+
+API and step structure of vllm/engine/llm_engine.py:150-633 (from_engine_args, add_request,
+abort_request, step, has_unfinished_requests); stop logic of _check_stop (:755-784).  Beam
+search and n > 1 forking are outside this build (one sequence per request).
+"""
+import time
+from typing import Dict, Iterable, List, Optional, Union
+
+from ..config import CacheConfig, DeviceConfig, ModelConfig, ParallelConfig, SchedulerConfig
+from ..core.scheduler import Scheduler, SchedulerOutputs
+from ..outputs import RequestOutput
+from ..sampling_params import SamplingParams
+from ..sequence import (SamplerOutput, Sequence, SequenceGroup, SequenceGroupMetadata, SequenceStatus)
+from .arg_utils import EngineArgs
+from .metrics import StatLogger, Stats
+
+
+class LLMEngine:
+    def __init__(self, model_config: ModelConfig, cache_config: CacheConfig, parallel_config: ParallelConfig,
+                 scheduler_config: SchedulerConfig, device_config: DeviceConfig, executor_class=None,
+                 log_stats: bool = False, tokenizer=None, num_gpu_blocks_override: Optional[int] = None,
+                 executor=None) -> None:
+        self.model_config = model_config
+        self.cache_config = cache_config
+        self.parallel_config = parallel_config
+        self.scheduler_config = scheduler_config
+        self.device_config = device_config
+        self.log_stats = log_stats
+        self.tokenizer = tokenizer
+        self.seq_counter = 0
+        if executor is not None:
+            self.model_executor = executor
+        else:
+            if executor_class is None:
+                if parallel_config.world_size > 1:
+                    from ..executor.splitwise_executor import SplitwiseExecutor
+                    executor_class = SplitwiseExecutor
+                else:
+                    from ..executor.gpu_executor import GPUExecutor
+                    executor_class = GPUExecutor
+            self.model_executor = executor_class(model_config, cache_config, parallel_config, scheduler_config,
+                                                 device_config, num_gpu_blocks_override=num_gpu_blocks_override)
+        self.scheduler = Scheduler(scheduler_config, cache_config, None,
+                                   track_prompt_blocks=parallel_config.sep_prompt_token)
+        self.stat_logger = StatLogger(local_interval=5.0) if log_stats else None
+
+    @classmethod
+    def from_engine_args(cls, engine_args: EngineArgs, **kwargs) -> "LLMEngine":
+        configs = engine_args.create_engine_configs()
+        return cls(*configs, num_gpu_blocks_override=engine_args.num_gpu_blocks_override, **kwargs)
+
+    # ----------------------------------------------------------------- requests
+    def add_request(self, request_id: str, prompt: Optional[str], sampling_params: SamplingParams,
+                    prompt_token_ids: Optional[List[int]] = None, arrival_time: Optional[float] = None) -> None:
+        if arrival_time is None:
+            arrival_time = time.monotonic()
+        if prompt_token_ids is None:
+            if self.tokenizer is None:
+                raise ValueError("prompt_token_ids must be given: no tokenizer is attached to this engine")
+            prompt_token_ids = self.tokenizer.encode(prompt)
+        if sampling_params.n != 1 or sampling_params.best_of != 1:
+            raise NotImplementedError("n > 1 / best_of > 1 are outside the scope of this build")
+        eos = getattr(self.tokenizer, "eos_token_id", None)
+        seq = Sequence(self.seq_counter, prompt, list(prompt_token_ids), self.cache_config.block_size, eos)
+        self.seq_counter += 1
+        self.scheduler.add_seq_group(SequenceGroup(request_id, [seq], sampling_params, arrival_time))
+
+    def abort_request(self, request_id: Union[str, Iterable[str]]) -> None:
+        self.scheduler.abort_seq_group(request_id)
+
+    def get_num_unfinished_requests(self) -> int:
+        return self.scheduler.get_num_unfinished_seq_groups()
+
+    def has_unfinished_requests(self) -> bool:
+        return self.scheduler.has_unfinished_seqs()
+
+    # --------------------------------------------------------------------- step
+    def _check_stop(self, seq: Sequence, params: SamplingParams) -> None:
+        last = seq.get_last_token_id()
+        if last in params.stop_token_ids:
+            seq.status = SequenceStatus.FINISHED_STOPPED
+            return
+        if seq.get_len() > self.scheduler_config.max_model_len:
+            seq.status = SequenceStatus.FINISHED_LENGTH_CAPPED
+            return
+        if params.max_tokens is not None and seq.get_output_len() == params.max_tokens:
+            seq.status = SequenceStatus.FINISHED_LENGTH_CAPPED
+            return
+        if not params.ignore_eos and seq.eos_token_id is not None and last == seq.eos_token_id:
+            seq.status = SequenceStatus.FINISHED_STOPPED
+
+    def _process_model_outputs(self, output: SamplerOutput, scheduler_outputs: SchedulerOutputs,
+                               groups: Optional[List[SequenceGroup]] = None) -> List[RequestOutput]:
+        now = time.time()
+        scheduled = list(scheduler_outputs.scheduled_seq_groups) if groups is None else groups
+        for group, out in zip(scheduled, output):
+            seq = group.get_seqs(status=SequenceStatus.RUNNING)[0]
+            sample = out.samples[0]
+            seq.append_token_id(sample.output_token, sample.logprobs)
+            if self.tokenizer is not None:
+                seq.output_text = self.tokenizer.decode(seq.get_output_token_ids())
+            self._check_stop(seq, group.sampling_params)
+            if seq.is_finished():
+                self.scheduler.free_seq(seq)
+            group.maybe_set_first_token_time(now)
+        self.scheduler.free_finished_seq_groups()
+        request_outputs = [RequestOutput.from_seq_group(g) for g in scheduled]
+        request_outputs += [RequestOutput.from_seq_group(g) for g in scheduler_outputs.ignored_seq_groups]
+        if self.stat_logger is not None:
+            self.stat_logger.log(self._get_stats(scheduler_outputs, scheduled, now))
+        return request_outputs
+
+    def step(self) -> List[RequestOutput]:
+        """One scheduling decision, one model step on the executor, outputs appended
+        (vllm/engine/llm_engine.py:571-633)."""
+        metas, scheduler_outputs = self.scheduler.schedule()
+        if not scheduler_outputs.is_empty():
+            output = self.model_executor.execute_model(
+                metas, scheduler_outputs.blocks_to_swap_in, scheduler_outputs.blocks_to_swap_out,
+                scheduler_outputs.blocks_to_copy, scheduler_outputs.blocks_to_nw)
+        else:
+            output = SamplerOutput([])
+        return self._process_model_outputs(output, scheduler_outputs)
+
+    def _get_stats(self, scheduler_outputs: SchedulerOutputs, scheduled: List[SequenceGroup], now: float) -> Stats:
+        total = self.cache_config.num_gpu_blocks or 1
+        free = self.scheduler.block_manager.get_num_free_gpu_blocks()
+        prompt_tokens = scheduler_outputs.num_batched_tokens if scheduler_outputs.prompt_run else 0
+        gen_tokens = 0 if scheduler_outputs.prompt_run else scheduler_outputs.num_batched_tokens
+        ttft, tpot, e2e = [], [], []
+        for g in scheduled:
+            latency = g.get_last_latency(now)
+            (ttft if scheduler_outputs.prompt_run else tpot).append(latency)
+            if g.is_finished():
+                e2e.append(now - g.metrics.arrival_time)
+        return Stats(now=now, num_running=len(self.scheduler.running), num_swapped=len(self.scheduler.swapped),
+                     num_waiting=len(self.scheduler.waiting), gpu_cache_usage=1.0 - free / total,
+                     cpu_cache_usage=0.0, num_prompt_tokens=prompt_tokens, num_generation_tokens=gen_tokens,
+                     time_to_first_tokens=ttft, time_per_output_tokens=tpot, time_e2e_requests=e2e)
+
+    def check_health(self) -> None:
+        self.model_executor.check_health()

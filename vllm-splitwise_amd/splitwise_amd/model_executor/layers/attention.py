@@ -1,0 +1,124 @@
+"""Attention layer: KV-cache write, Splitwise KV push, prompt / decode attention.
+
+Order of operations restated from the reference's backends
+(vllm/model_executor/layers/attention/backends/xformers.py:70-191, flash_attn.py:77-125):
+  1. reshape_and_cache of the step's keys / values (skipped during the profiling run,
+     where no cache exists yet);
+  2. prompt run on a prompt-pool worker: for every hand-off slot and block run in
+     ``blocks_to_nw``, push this layer's K and V blocks to the paired token worker
+     (ordered after step 1 on the same stream, before the layer's attention finishes);
+  3. prompt run -> causal self-attention over the prompt tokens, decode run -> paged
+     attention over the block tables (v1 / v2 choice: ops/paged_attn.py:39-111).
+"""
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+
+from ... import _C
+from ..input_metadata import InputMetadata
+
+_PARTITION_SIZE = 512          # must match the partition size of sw_paged_attention_v2
+_SUPPORTED_HEAD_SIZES = [64, 80, 96, 112, 128, 256]
+
+
+class PagedAttentionImpl:
+    """Static helpers with the reference's names (ops/paged_attn.py:15-138)."""
+
+    @staticmethod
+    def get_supported_head_sizes() -> List[int]:
+        return list(_SUPPORTED_HEAD_SIZES)
+
+    @staticmethod
+    def reshape_and_cache(key, value, key_cache, value_cache, input_metadata: InputMetadata) -> None:
+        _C.cache_ops.reshape_and_cache(key, value, key_cache, value_cache, input_metadata.slot_mapping.flatten(),
+                                       input_metadata.kv_cache_dtype)
+
+    @staticmethod
+    def use_v1(num_seqs: int, num_heads: int, num_kv_heads: int, max_context_len: int) -> bool:
+        """One workgroup serves a (sequence, kv head) pair -- all query heads of a GQA group at
+        once -- so the unpartitioned kernel fills the 256 CUs only with enough such pairs; below
+        that the context is split into 512-token partitions (v2).  (The reference's rule,
+        ops/paged_attn.py:62-63, is tuned for 128-thread blocks per query head and a shared-memory
+        cap that does not exist here.)"""
+        if max_context_len <= _PARTITION_SIZE:
+            return True
+        return num_seqs * num_kv_heads >= 1024
+
+    @staticmethod
+    def forward_decode(query, key_cache, value_cache, input_metadata: InputMetadata, num_kv_heads: int,
+                       scale: float, alibi_slopes: Optional[torch.Tensor], workspace=None) -> torch.Tensor:
+        output = torch.empty_like(query)
+        block_size = value_cache.shape[3]
+        num_seqs, num_heads, head_size = query.shape
+        max_ctx = input_metadata.max_context_len
+        if PagedAttentionImpl.use_v1(num_seqs, num_heads, num_kv_heads, max_ctx):
+            _C.ops.paged_attention_v1(output, query, key_cache, value_cache, num_kv_heads, scale,
+                                      input_metadata.block_tables, input_metadata.context_lens, block_size,
+                                      max_ctx, alibi_slopes, input_metadata.kv_cache_dtype)
+        else:
+            parts = (max_ctx + _PARTITION_SIZE - 1) // _PARTITION_SIZE
+            tmp_output = torch.empty((num_seqs, num_heads, parts, head_size), dtype=output.dtype,
+                                     device=output.device)
+            exp_sums = torch.empty((num_seqs, num_heads, parts), dtype=torch.float32, device=output.device)
+            max_logits = torch.empty_like(exp_sums)
+            _C.ops.paged_attention_v2(output, exp_sums, max_logits, tmp_output, query, key_cache, value_cache,
+                                      num_kv_heads, scale, input_metadata.block_tables,
+                                      input_metadata.context_lens, block_size, max_ctx, alibi_slopes,
+                                      input_metadata.kv_cache_dtype)
+        return output
+
+
+class Attention(nn.Module):
+    """The class name matters: the worker finds the layers to hook the KV transport into by it
+    (vllm/worker/worker.py:160-169)."""
+
+    def __init__(self, num_heads: int, head_size: int, scale: float, num_kv_heads: Optional[int] = None,
+                 alibi_slopes: Optional[List[float]] = None, sliding_window: Optional[int] = None) -> None:
+        super().__init__()
+        self.num_heads = num_heads
+        self.head_size = head_size
+        self.scale = float(scale)
+        self.num_kv_heads = num_heads if num_kv_heads is None else num_kv_heads
+        self.sliding_window = sliding_window
+        self.alibi_slopes = (torch.tensor(alibi_slopes, dtype=torch.float32) if alibi_slopes is not None else None)
+        assert self.num_heads % self.num_kv_heads == 0
+        if head_size not in _SUPPORTED_HEAD_SIZES:
+            raise ValueError(f"Head size {head_size} is not supported by PagedAttention. "
+                             f"Supported head sizes are: {_SUPPORTED_HEAD_SIZES}.")
+        self.kvcache_comm_manager = None
+        self.layer_id: Optional[int] = None
+
+    def set_kvcache_comm_manager(self, manager) -> None:
+        self.kvcache_comm_manager = manager
+
+    def forward(self, query: torch.Tensor, key: torch.Tensor, value: torch.Tensor,
+                key_cache: Optional[torch.Tensor], value_cache: Optional[torch.Tensor],
+                input_metadata: InputMetadata) -> torch.Tensor:
+        """query [..., H*D], key / value [..., KVH*D] (views of the fused qkv output are fine)."""
+        out_shape = query.shape
+        query = query.reshape(-1, self.num_heads, self.head_size) if query.dim() != 2 else \
+            query.view(-1, self.num_heads, self.head_size)
+        key = key.view(-1, self.num_kv_heads, self.head_size) if key.dim() == 2 else \
+            key.reshape(-1, self.num_kv_heads, self.head_size)
+        value = value.view(-1, self.num_kv_heads, self.head_size) if value.dim() == 2 else \
+            value.reshape(-1, self.num_kv_heads, self.head_size)
+        if self.alibi_slopes is not None and self.alibi_slopes.device != query.device:
+            self.alibi_slopes = self.alibi_slopes.to(query.device)
+
+        if key_cache is not None and value_cache is not None:
+            PagedAttentionImpl.reshape_and_cache(key, value, key_cache, value_cache, input_metadata)
+
+        if input_metadata.is_prompt:
+            if input_metadata.blocks_to_nw and self.kvcache_comm_manager is not None:
+                for sem_id, runs in input_metadata.blocks_to_nw.items():
+                    for block_start, num_blocks in runs:
+                        self.kvcache_comm_manager.put(sem_id, self.layer_id, block_start, num_blocks)
+            output = torch.empty_like(query)
+            _C.ops.prefill_attention(output, query, key, value, input_metadata.start_loc,
+                                     input_metadata.prompt_lens, input_metadata.max_seq_len, self.scale,
+                                     self.alibi_slopes, self.sliding_window)
+        else:
+            output = PagedAttentionImpl.forward_decode(query, key_cache, value_cache, input_metadata,
+                                                       self.num_kv_heads, self.scale, self.alibi_slopes)
+        return output.view(out_shape[:-1] + (self.num_heads * self.head_size,))

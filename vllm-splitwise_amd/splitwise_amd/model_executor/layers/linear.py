@@ -1,0 +1,122 @@
+"""Linear layers with a pluggable weight format.
+
+The plug-in point mirrors vllm/model_executor/layers/linear.py:29-76: a ``LinearMethodBase``
+creates the parameters of a layer (``create_weights``) and applies them (``apply_weights``);
+quantised formats (GPTQ, AWQ) register their own method.  Tensor parallelism is expressed by
+the layer kind: column-parallel layers shard the output dimension, row-parallel layers the
+input dimension and all-reduce the result over the TP group (:580-633).
+"""
+from typing import Any, Dict, List, Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ..parallel_state import get_tensor_model_parallel_world_size, tensor_model_parallel_all_reduce
+
+
+class LinearMethodBase:
+    def create_weights(self, input_size_per_partition: int, output_size_per_partition: int, input_size: int,
+                       output_size: int, params_dtype: torch.dtype) -> Dict[str, Any]:
+        raise NotImplementedError
+
+    def apply_weights(self, weights: Dict[str, torch.Tensor], x: torch.Tensor,
+                      bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+        raise NotImplementedError
+
+
+class UnquantizedLinearMethod(LinearMethodBase):
+    """Dense weights [out, in]; the GEMM is the ROCm BLAS library's (hipBLASLt via torch)."""
+
+    def create_weights(self, input_size_per_partition, output_size_per_partition, input_size, output_size,
+                       params_dtype):
+        weight = nn.Parameter(torch.empty(output_size_per_partition, input_size_per_partition,
+                                          dtype=params_dtype), requires_grad=False)
+        return {"weight": weight}
+
+    def apply_weights(self, weights, x, bias=None):
+        return F.linear(x, weights["weight"], bias)
+
+
+class _LinearBase(nn.Module):
+    def __init__(self, in_per_part: int, out_per_part: int, input_size: int, output_size: int, bias: bool,
+                 params_dtype: torch.dtype, linear_method: Optional[LinearMethodBase]) -> None:
+        super().__init__()
+        self.input_size = input_size
+        self.output_size = output_size
+        self.linear_method = linear_method or UnquantizedLinearMethod()
+        self.linear_weights = self.linear_method.create_weights(in_per_part, out_per_part, input_size,
+                                                                output_size, params_dtype)
+        for name, w in self.linear_weights.items():
+            if isinstance(w, torch.Tensor):
+                self.register_parameter(name, w if isinstance(w, nn.Parameter) else nn.Parameter(w, False))
+        self.bias = nn.Parameter(torch.zeros(out_per_part, dtype=params_dtype), requires_grad=False) if bias else None
+
+    def _weights(self) -> Dict[str, Any]:
+        # parameters may have been moved (.to(device)): always hand the live tensors to the method
+        live = dict(self.linear_weights)
+        for name in live:
+            if name in self._parameters:
+                live[name] = self._parameters[name]
+        return live
+
+
+class ColumnParallelLinear(_LinearBase):
+    """Y = X W^T with W sharded along the output dimension."""
+
+    def __init__(self, input_size: int, output_size: int, bias: bool = False,
+                 params_dtype: torch.dtype = torch.float16, linear_method: Optional[LinearMethodBase] = None):
+        tp = get_tensor_model_parallel_world_size()
+        assert output_size % tp == 0
+        super().__init__(input_size, output_size // tp, input_size, output_size, bias, params_dtype, linear_method)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return self.linear_method.apply_weights(self._weights(), x, self.bias)
+
+
+class MergedColumnParallelLinear(ColumnParallelLinear):
+    """Several column-parallel projections of the same input fused into one GEMM (gate_up_proj)."""
+
+    def __init__(self, input_size: int, output_sizes: List[int], bias: bool = False,
+                 params_dtype: torch.dtype = torch.float16, linear_method: Optional[LinearMethodBase] = None):
+        self.output_sizes = output_sizes
+        super().__init__(input_size, sum(output_sizes), bias, params_dtype, linear_method)
+
+
+class QKVParallelLinear(ColumnParallelLinear):
+    """Fused q / k / v projection; kv heads are replicated when there are fewer than TP ranks
+    (vllm/model_executor/layers/linear.py:380-420)."""
+
+    def __init__(self, hidden_size: int, head_size: int, total_num_heads: int,
+                 total_num_kv_heads: Optional[int] = None, bias: bool = False,
+                 params_dtype: torch.dtype = torch.float16, linear_method: Optional[LinearMethodBase] = None):
+        tp = get_tensor_model_parallel_world_size()
+        total_num_kv_heads = total_num_heads if total_num_kv_heads is None else total_num_kv_heads
+        self.num_heads = total_num_heads // tp
+        if tp >= total_num_kv_heads:
+            self.num_kv_heads, self.num_kv_head_replicas = 1, tp // total_num_kv_heads
+        else:
+            self.num_kv_heads, self.num_kv_head_replicas = total_num_kv_heads // tp, 1
+        out = (self.num_heads + 2 * self.num_kv_heads) * tp * head_size
+        super().__init__(hidden_size, out, bias, params_dtype, linear_method)
+
+
+class RowParallelLinear(_LinearBase):
+    """Y = X W^T with W sharded along the input dimension; partial sums are all-reduced."""
+
+    def __init__(self, input_size: int, output_size: int, bias: bool = False,
+                 params_dtype: torch.dtype = torch.float16, linear_method: Optional[LinearMethodBase] = None,
+                 reduce_results: bool = True):
+        tp = get_tensor_model_parallel_world_size()
+        assert input_size % tp == 0
+        self.reduce_results = reduce_results
+        self.tp_size = tp
+        super().__init__(input_size // tp, output_size, input_size, output_size, bias, params_dtype, linear_method)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        out = self.linear_method.apply_weights(self._weights(), x, None)
+        if self.reduce_results and self.tp_size > 1:
+            out = tensor_model_parallel_all_reduce(out)
+        if self.bias is not None:
+            out = out + self.bias
+        return out

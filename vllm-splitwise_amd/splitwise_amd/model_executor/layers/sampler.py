@@ -1,0 +1,121 @@
+"""Next-token sampling.
+
+Restates the parts of vllm/model_executor/layers/sampler.py the configurations use:
+hidden states are pruned to the rows that are sampled (:135-140), logits = h @ E^T (:108-121),
+temperature / top-k / top-p filtering (:79-99, :207-238), greedy = argmax of the log-probs
+(:417), random = multinomial over the filtered distribution.  Under tensor parallelism the
+vocabulary-sharded logits are gathered (sampler.py:44-57).
+"""
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from ...sampling_params import SamplingParams, SamplingType
+from ...sequence import Logprob, SamplerOutput, SequenceData, SequenceGroupOutput, SequenceOutput
+from ..parallel_state import tensor_model_parallel_all_gather
+
+_EPS = 1e-5
+
+
+class SamplingMetadata:
+    """What the sampler needs besides the hidden states (vllm/model_executor/sampling_metadata.py)."""
+
+    def __init__(self, seq_groups: Optional[List[Tuple[List[int], SamplingParams]]],
+                 seq_data: Optional[Dict[int, SequenceData]], prompt_lens: Optional[List[int]],
+                 selected_token_indices: torch.Tensor, generators=None, perform_sampling: bool = True) -> None:
+        self.seq_groups = seq_groups
+        self.seq_data = seq_data
+        self.prompt_lens = prompt_lens
+        self.selected_token_indices = selected_token_indices
+        self.generators = generators
+        self.perform_sampling = perform_sampling
+
+
+class Sampler(nn.Module):
+    def __init__(self, vocab_size: int, org_vocab_size: Optional[int] = None) -> None:
+        super().__init__()
+        self.vocab_size = vocab_size
+        self.org_vocab_size = org_vocab_size or vocab_size
+
+    def _get_logits(self, hidden_states: torch.Tensor, embedding: torch.Tensor,
+                    embedding_bias: Optional[torch.Tensor]) -> torch.Tensor:
+        logits = torch.matmul(hidden_states, embedding.t())
+        if embedding_bias is not None:
+            logits += embedding_bias
+        logits = tensor_model_parallel_all_gather(logits)
+        return logits[:, :self.org_vocab_size]
+
+    def forward(self, embedding: torch.Tensor, hidden_states: torch.Tensor,
+                sampling_metadata: SamplingMetadata,
+                embedding_bias: Optional[torch.Tensor] = None) -> Optional[SamplerOutput]:
+        hidden_states = hidden_states.reshape(-1, hidden_states.shape[-1])
+        hidden_states = hidden_states.index_select(0, sampling_metadata.selected_token_indices)
+        logits = self._get_logits(hidden_states, embedding, embedding_bias)
+        if not sampling_metadata.perform_sampling:
+            return None
+        return self.sample_from_logits(logits, sampling_metadata)
+
+    @staticmethod
+    def _apply_top_k_top_p(logits: torch.Tensor, top_ps: torch.Tensor, top_ks: torch.Tensor) -> torch.Tensor:
+        # ascending sort; mask everything below the k-th largest, then the low-probability tail
+        logits_sort, logits_idx = logits.sort(dim=-1, descending=False)
+        top_k_mask = logits_sort.size(1) - top_ks.to(torch.long)
+        top_k_mask = logits_sort.gather(1, top_k_mask.unsqueeze(dim=1))
+        logits_sort.masked_fill_(logits_sort < top_k_mask, -float("inf"))
+        probs_sum = logits_sort.softmax(dim=-1).cumsum(dim=-1)
+        top_p_mask = probs_sum <= 1 - top_ps.unsqueeze(dim=1)
+        top_p_mask[:, -1] = False                      # at least one token stays
+        logits_sort.masked_fill_(top_p_mask, -float("inf"))
+        return torch.empty_like(logits_sort).scatter_(dim=-1, index=logits_idx, src=logits_sort)
+
+    def sample_from_logits(self, logits: torch.Tensor, md: SamplingMetadata) -> SamplerOutput:
+        logits = logits.float()
+        rows: List[SamplingParams] = []
+        for seq_ids, params in md.seq_groups:
+            if params.prompt_logprobs is not None:
+                raise NotImplementedError("prompt_logprobs is outside the scope of this build")
+            rows.extend([params] * len(seq_ids))
+        assert len(rows) == logits.shape[0], (len(rows), logits.shape)
+        all_greedy = all(p.sampling_type == SamplingType.GREEDY for p in rows)
+        want_logprobs = any(p.logprobs is not None for p in rows)
+        if all_greedy and not want_logprobs:
+            # fast path: argmax of the logits equals argmax of the log-probs
+            next_ids = torch.argmax(logits, dim=-1)
+            chosen_lp = None
+        else:
+            temps = torch.tensor([p.temperature if p.temperature >= _EPS else 1.0 for p in rows],
+                                 dtype=torch.float32, device=logits.device)
+            if not torch.all(temps == 1.0):
+                logits = logits / temps.unsqueeze(1)
+            vocab = logits.shape[1]
+            if any(p.top_p < 1.0 - _EPS or (p.top_k != -1 and p.top_k != vocab) for p in rows):
+                top_ps = torch.tensor([p.top_p for p in rows], dtype=torch.float32, device=logits.device)
+                top_ks = torch.tensor([vocab if p.top_k == -1 else min(p.top_k, vocab) for p in rows],
+                                      dtype=torch.int32, device=logits.device)
+                logits = self._apply_top_k_top_p(logits, top_ps, top_ks)
+            probs = torch.softmax(logits, dim=-1)
+            logprobs = torch.log_softmax(logits, dim=-1)
+            greedy_ids = torch.argmax(logprobs, dim=-1)
+            if all_greedy:
+                next_ids = greedy_ids
+            else:
+                random_ids = torch.multinomial(probs, 1).squeeze(1)
+                # rows of seeded requests redraw from their own generator (sampler.py:370-383)
+                for row_idx, g in (md.generators or {}).items():
+                    random_ids[row_idx] = torch.multinomial(probs[row_idx], 1, generator=g)[0]
+                is_greedy = torch.tensor([p.sampling_type == SamplingType.GREEDY for p in rows],
+                                         device=logits.device)
+                next_ids = torch.where(is_greedy, greedy_ids, random_ids)
+            chosen_lp = logprobs.gather(1, next_ids.unsqueeze(1)).squeeze(1).tolist()
+        ids = next_ids.tolist()                            # the one device -> host sync of the step
+        outputs: List[SequenceGroupOutput] = []
+        row = 0
+        for seq_ids, params in md.seq_groups:
+            samples = []
+            for seq_id in seq_ids:
+                lp = 0.0 if chosen_lp is None else chosen_lp[row]
+                samples.append(SequenceOutput(seq_id, ids[row], {ids[row]: Logprob(lp)}))
+                row += 1
+            outputs.append(SequenceGroupOutput(samples, None))
+        return SamplerOutput(outputs=outputs)

@@ -1,0 +1,84 @@
+"""Tensor-parallel and stage (prompt pool / token pool) process groups.
+
+Group layout of vllm/model_executor/parallel_utils/parallel_state.py:22-103: consecutive
+blocks of ``tensor_model_parallel_size`` ranks form TP groups; with ``sep_prompt_token`` the
+first half of the world is the prompt stage and the second half the token stage, and the
+stage group is what step metadata is broadcast over.  Collectives are RCCL's through
+``torch.distributed`` (backend "nccl" on ROCm) -- or gloo in CPU tests.
+"""
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+_TP_GROUP = None
+_STAGE_GROUP = None
+_TP_WORLD = 1
+_TP_RANK = 0
+
+
+def initialize_model_parallel(tensor_model_parallel_size: int = 1, sep_prompt_token: bool = False,
+                              backend: Optional[str] = None) -> None:
+    global _TP_GROUP, _STAGE_GROUP, _TP_WORLD, _TP_RANK
+    if not dist.is_initialized():
+        assert tensor_model_parallel_size == 1, "torch.distributed must be initialised for TP > 1"
+        _TP_WORLD, _TP_RANK = 1, 0
+        return
+    world, rank = dist.get_world_size(), dist.get_rank()
+    assert world % tensor_model_parallel_size == 0
+    for i in range(world // tensor_model_parallel_size):
+        ranks = list(range(i * tensor_model_parallel_size, (i + 1) * tensor_model_parallel_size))
+        group = dist.new_group(ranks, backend=backend)
+        if rank in ranks:
+            _TP_GROUP = group
+            _TP_RANK = ranks.index(rank)
+    _TP_WORLD = tensor_model_parallel_size
+    if sep_prompt_token:
+        half = world // 2
+        for ranks in (list(range(0, half)), list(range(half, world))):
+            group = dist.new_group(ranks, backend=backend)
+            if rank in ranks:
+                _STAGE_GROUP = group
+    else:
+        _STAGE_GROUP = dist.group.WORLD
+
+
+def destroy_model_parallel() -> None:
+    global _TP_GROUP, _STAGE_GROUP, _TP_WORLD, _TP_RANK
+    _TP_GROUP = _STAGE_GROUP = None
+    _TP_WORLD, _TP_RANK = 1, 0
+
+
+def get_tensor_model_parallel_world_size() -> int:
+    return _TP_WORLD
+
+
+def get_tensor_model_parallel_rank() -> int:
+    return _TP_RANK
+
+
+def get_tensor_model_parallel_group():
+    return _TP_GROUP
+
+
+def get_stage_parallel_group():
+    return _STAGE_GROUP
+
+
+def tensor_model_parallel_all_reduce(x: torch.Tensor) -> torch.Tensor:
+    """In-place SUM over the TP group (communication_op.py:19-43)."""
+    if _TP_WORLD == 1:
+        return x
+    dist.all_reduce(x, group=_TP_GROUP)
+    return x
+
+
+def tensor_model_parallel_all_gather(x: torch.Tensor, dim: int = -1) -> torch.Tensor:
+    """communication_op.py:46-71."""
+    if _TP_WORLD == 1:
+        return x
+    if dim < 0:
+        dim += x.dim()
+    parts = [torch.empty_like(x) for _ in range(_TP_WORLD)]
+    dist.all_gather(parts, x.contiguous(), group=_TP_GROUP)
+    return torch.cat(parts, dim=dim)

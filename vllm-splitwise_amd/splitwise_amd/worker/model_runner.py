@@ -1,0 +1,336 @@
+"""Turns scheduled sequence groups into device tensors and runs the model.
+
+Index arithmetic restated from vllm/worker/model_runner.py:126-399: slot of token i of a
+sequence = block_table[i // block_size] * block_size + i % block_size; padding slots are -1;
+a decode step feeds the last token at position len - 1 with context_len = len (capped by the
+sliding window).  Two prompt layouts are produced:
+
+  * ``_prepare_prompt``   the reference's padded [num_prompts, max_prompt_len] batch
+                          (kept bit-identical; used by the parity tests and by callers that
+                          expect the reference's shapes);
+  * ``_prepare_prompt_packed``  the layout the engine runs: prompts back to back in one
+                          token dimension, each starting at a multiple of 16 rows so the KV
+                          write lands in whole cache-block pieces; no compute is spent on
+                          per-prompt padding to the longest prompt.
+
+Decode steps are replayed from HIP graphs captured per padded batch size
+(vllm/worker/model_runner.py:701-876 does the same with CUDA graphs); the hand-off wait of
+the token pool stays outside the graph (vllm/worker/worker.py:318-325).
+"""
+import time
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from ..config import DeviceConfig, ModelConfig, ParallelConfig, SchedulerConfig
+from ..model_executor.input_metadata import InputMetadata
+from ..model_executor.layers.sampler import SamplingMetadata
+from ..model_executor.model_loader import get_model
+from ..sampling_params import SamplingParams
+from ..sequence import SamplerOutput, SequenceData, SequenceGroupMetadata
+
+_PAD_SLOT_ID = -1
+_PROMPT_ROW_ALIGN = 16
+# decode batch sizes with a captured graph: 1, 2, 4, 8, 16, 24, ..., 256
+_BATCH_SIZES_TO_CAPTURE = [1, 2, 4] + [8 * i for i in range(1, 33)]
+
+
+def _get_graph_batch_size(batch_size: int) -> int:
+    if batch_size <= 2:
+        return batch_size
+    if batch_size <= 4:
+        return 4
+    return (batch_size + 7) // 8 * 8
+
+
+def _pad_2d(rows: List[List[int]], width: int, pad: int, dtype) -> np.ndarray:
+    out = np.full((len(rows), width), pad, dtype=dtype)
+    for i, r in enumerate(rows):
+        out[i, :len(r)] = r
+    return out
+
+
+class ModelRunner:
+    def __init__(self, model_config: Optional[ModelConfig], parallel_config: Optional[ParallelConfig],
+                 scheduler_config: Optional[SchedulerConfig], device_config: Optional[DeviceConfig],
+                 kv_cache_dtype: str = "auto", is_driver_worker: bool = False) -> None:
+        self.model_config = model_config
+        self.parallel_config = parallel_config
+        self.scheduler_config = scheduler_config
+        self.device_config = device_config if device_config is not None else DeviceConfig("cpu")
+        self.device = self.device_config.device
+        self.is_driver_worker = is_driver_worker
+        self.driver_rank = 0
+        self.sliding_window = model_config.get_sliding_window() if model_config is not None else None
+        self.kv_cache_dtype = kv_cache_dtype
+        self.model = None
+        self.block_size: Optional[int] = None
+        self.graph_runners: Dict[int, "HIPGraphRunner"] = {}
+        self.graph_memory_pool = None
+        self.max_context_len_to_capture = model_config.max_context_len_to_capture if model_config else 0
+        self.enforce_eager = model_config.enforce_eager if model_config is not None else True
+
+    # ------------------------------------------------------------------ set-up
+    def load_model(self) -> None:
+        self.model = get_model(self.model_config, self.device)
+
+    def set_block_size(self, block_size: int) -> None:
+        self.block_size = block_size
+
+    @property
+    def vocab_size(self) -> int:
+        return self.model_config.get_vocab_size()
+
+    def _to_device(self, array: np.ndarray, dtype: torch.dtype) -> torch.Tensor:
+        t = torch.from_numpy(np.ascontiguousarray(array)).to(dtype)
+        if self.device.type == "cuda":
+            return t.pin_memory().to(self.device, non_blocking=True)
+        return t
+
+    # ----------------------------------------------------------------- prompts
+    def _prompt_rows(self, metas: List[SequenceGroupMetadata]):
+        """Per prompt: (tokens, positions, slots)."""
+        rows = []
+        for meta in metas:
+            assert meta.is_prompt
+            seq_ids = list(meta.seq_data.keys())
+            assert len(seq_ids) == 1
+            seq_id = seq_ids[0]
+            tokens = meta.seq_data[seq_id].get_token_ids()
+            n = len(tokens)
+            if meta.block_tables is None:              # profiling run: nothing is cached
+                slots = [_PAD_SLOT_ID] * n
+            else:
+                table = meta.block_tables[seq_id]
+                bs = self.block_size
+                # with a sliding window only the last `window` tokens are kept (model_runner.py:195-209)
+                start = 0 if self.sliding_window is None else max(0, n - self.sliding_window)
+                slots = [_PAD_SLOT_ID if i < start else table[i // bs] * bs + i % bs for i in range(n)]
+            rows.append((tokens, list(range(n)), slots))
+        return rows
+
+    def _prepare_prompt(self, metas: List[SequenceGroupMetadata]):
+        """Padded layout, identical to the reference's tensors (model_runner.py:126-272).
+        -> (input_tokens [B, L], input_positions [B, L], InputMetadata, prompt_lens, subquery_lens)"""
+        assert len(metas) > 0
+        rows = self._prompt_rows(metas)
+        prompt_lens = [len(r[0]) for r in rows]
+        max_len = max(prompt_lens)
+        assert max_len > 0
+        tokens = self._to_device(_pad_2d([r[0] for r in rows], max_len, 0, np.int64), torch.long)
+        positions = self._to_device(_pad_2d([r[1] for r in rows], max_len, 0, np.int64), torch.long)
+        slots = self._to_device(_pad_2d([r[2] for r in rows], max_len, _PAD_SLOT_ID, np.int64), torch.long)
+        start_loc = self._to_device(np.arange(0, len(rows) * max_len, max_len, dtype=np.int32), torch.int32)
+        md = InputMetadata(
+            is_prompt=True, slot_mapping=slots,
+            prompt_lens=self._to_device(np.asarray(prompt_lens, dtype=np.int32), torch.int32),
+            max_seq_len=max_len, start_loc=start_loc, max_context_len=None,
+            context_lens=self._to_device(np.zeros(len(rows), dtype=np.int32), torch.int32),
+            block_tables=torch.empty((len(rows), 0), dtype=torch.int32, device=self.device),
+            use_cuda_graph=False, kv_cache_dtype=self.kv_cache_dtype)
+        return tokens, positions, md, prompt_lens, list(prompt_lens)
+
+    def _prepare_prompt_packed(self, metas: List[SequenceGroupMetadata]):
+        """-> (input_tokens [T], input_positions [T], InputMetadata, prompt_lens, row starts)."""
+        rows = self._prompt_rows(metas)
+        prompt_lens = [len(r[0]) for r in rows]
+        starts, total = [], 0
+        for n in prompt_lens:
+            starts.append(total)
+            total += -(-n // _PROMPT_ROW_ALIGN) * _PROMPT_ROW_ALIGN
+        tokens = np.zeros(total, dtype=np.int64)
+        positions = np.zeros(total, dtype=np.int64)
+        slots = np.full(total, _PAD_SLOT_ID, dtype=np.int64)
+        for (tok, pos, slot), s in zip(rows, starts):
+            n = len(tok)
+            tokens[s:s + n] = tok
+            positions[s:s + n] = pos
+            slots[s:s + n] = slot
+        md = InputMetadata(
+            is_prompt=True, slot_mapping=self._to_device(slots, torch.long),
+            prompt_lens=self._to_device(np.asarray(prompt_lens, dtype=np.int32), torch.int32),
+            max_seq_len=max(prompt_lens), start_loc=self._to_device(np.asarray(starts, dtype=np.int32), torch.int32),
+            max_context_len=None, context_lens=None, block_tables=None, use_cuda_graph=False,
+            kv_cache_dtype=self.kv_cache_dtype)
+        return (self._to_device(tokens, torch.long), self._to_device(positions, torch.long), md, prompt_lens,
+                starts)
+
+    # ------------------------------------------------------------------ decode
+    def _prepare_decode(self, metas: List[SequenceGroupMetadata]):
+        """-> (input_tokens [B, 1], input_positions [B, 1], InputMetadata); model_runner.py:274-399."""
+        assert len(metas) > 0
+        tokens: List[int] = []
+        positions: List[int] = []
+        slots: List[int] = []
+        context_lens: List[int] = []
+        tables: List[List[int]] = []
+        bs = self.block_size
+        for meta in metas:
+            assert not meta.is_prompt
+            for seq_id, data in meta.seq_data.items():
+                seq_len = data.get_len()
+                pos = seq_len - 1
+                tokens.append(data.get_last_token_id())
+                positions.append(pos)
+                context_lens.append(seq_len if self.sliding_window is None else min(seq_len, self.sliding_window))
+                table = meta.block_tables[seq_id]
+                slots.append(table[pos // bs] * bs + pos % bs)
+                if self.sliding_window is not None:
+                    table = table[-(self.sliding_window // bs):]
+                tables.append(table)
+        batch = len(tokens)
+        max_ctx = max(context_lens)
+        use_graph = (not self.enforce_eager and bool(self.graph_runners)
+                     and batch <= _BATCH_SIZES_TO_CAPTURE[-1] and max_ctx <= self.max_context_len_to_capture)
+        if use_graph:
+            padded = _get_graph_batch_size(batch)
+            for _ in range(padded - batch):
+                tokens.append(0)
+                positions.append(0)
+                slots.append(_PAD_SLOT_ID)
+                context_lens.append(1)
+                tables.append([])
+            width = -(-self.max_context_len_to_capture // bs)
+        else:
+            width = max(len(t) for t in tables)
+        md = InputMetadata(
+            is_prompt=False, slot_mapping=self._to_device(np.asarray(slots, dtype=np.int64).reshape(-1, 1), torch.long),
+            prompt_lens=None, max_seq_len=None, start_loc=None, max_context_len=max_ctx,
+            context_lens=self._to_device(np.asarray(context_lens, dtype=np.int32), torch.int32),
+            block_tables=self._to_device(_pad_2d(tables, width, 0, np.int32), torch.int32),
+            use_cuda_graph=use_graph, kv_cache_dtype=self.kv_cache_dtype)
+        return (self._to_device(np.asarray(tokens, dtype=np.int64).reshape(-1, 1), torch.long),
+                self._to_device(np.asarray(positions, dtype=np.int64).reshape(-1, 1), torch.long), md)
+
+    # ---------------------------------------------------------------- sampling
+    def _prepare_sample(self, metas: List[SequenceGroupMetadata], last_token_rows: Optional[List[int]]):
+        """Rows of the hidden states to sample from: the last token of every prompt, or every row
+        of a decode step (model_runner.py:401-485 without prompt_logprobs)."""
+        seq_groups: List[Tuple[List[int], SamplingParams]] = []
+        selected: List[int] = []
+        generators: Dict[int, torch.Generator] = {}
+        seq_data: Dict[int, SequenceData] = {}
+        row = 0
+        for i, meta in enumerate(metas):
+            seq_ids = list(meta.seq_data.keys())
+            params = meta.sampling_params
+            seq_groups.append((seq_ids, params))
+            seq_data.update(meta.seq_data)
+            if meta.is_prompt:
+                selected.append(last_token_rows[i])
+                n_rows = 1
+            else:
+                selected.extend(range(row, row + len(seq_ids)))
+                n_rows = len(seq_ids)
+            if params.seed is not None:
+                if meta.state.generator is None:
+                    meta.state.generator = torch.Generator(device=self.device).manual_seed(params.seed)
+                for r in range(len(selected) - n_rows, len(selected)):
+                    generators[r] = meta.state.generator
+            row += n_rows
+        return SamplingMetadata(seq_groups, seq_data, None,
+                                self._to_device(np.asarray(selected, dtype=np.int64), torch.long), generators)
+
+    # --------------------------------------------------------------- execution
+    @torch.inference_mode()
+    def execute_model(self, metas: List[SequenceGroupMetadata], kv_caches, blocks_to_nw=None,
+                      prompt_layout: str = "packed") -> Optional[SamplerOutput]:
+        is_prompt = metas[0].is_prompt
+        if is_prompt:
+            if prompt_layout == "packed":
+                tokens, positions, md, prompt_lens, starts = self._prepare_prompt_packed(metas)
+                last_rows = [s + n - 1 for s, n in zip(starts, prompt_lens)]
+            else:
+                tokens, positions, md, prompt_lens, _ = self._prepare_prompt(metas)
+                width = tokens.shape[1]
+                last_rows = [i * width + n - 1 for i, n in enumerate(prompt_lens)]
+            sampling_md = self._prepare_sample(metas, last_rows)
+        else:
+            tokens, positions, md = self._prepare_decode(metas)
+            sampling_md = self._prepare_sample(metas, None)
+        md.blocks_to_nw = blocks_to_nw or {}
+        # the model sees one flat token dimension in every layout
+        if md.use_cuda_graph:
+            hidden = self.graph_runners[tokens.shape[0]](tokens, positions, kv_caches, md)
+        else:
+            hidden = self.model(tokens.view(-1), positions.view(-1), kv_caches, md)
+        return self.model.sample(hidden, sampling_md)
+
+    @torch.inference_mode()
+    def profile_run(self) -> None:
+        """One prompt step of the largest admissible batch without a KV cache, to find the peak
+        activation memory (model_runner.py:620-672)."""
+        params = SamplingParams(temperature=0.0, max_tokens=1)
+        max_tokens = self.scheduler_config.max_num_batched_tokens
+        max_seqs = self.scheduler_config.max_num_seqs
+        metas = []
+        for gid in range(max_seqs):
+            n = max_tokens // max_seqs + (gid < max_tokens % max_seqs)
+            if n == 0:
+                continue
+            metas.append(SequenceGroupMetadata(str(gid), True, {gid: SequenceData([0] * n)}, params, None))
+        num_layers = self.model_config.get_num_layers(self.parallel_config)
+        self.execute_model(metas, [(None, None)] * num_layers)
+        if self.device.type == "cuda":
+            torch.cuda.synchronize()
+
+    # --------------------------------------------------------------- HIP graphs
+    @torch.inference_mode()
+    def capture_model(self, kv_caches) -> None:
+        """Captures one decode graph per batch size, largest first so that the smaller ones reuse
+        its memory pool (model_runner.py:701-760)."""
+        assert not self.enforce_eager
+        t0 = time.perf_counter()
+        max_bs = max(_BATCH_SIZES_TO_CAPTURE)
+        max_blocks = -(-self.max_context_len_to_capture // self.block_size)
+        dev = self.device
+        tokens = torch.zeros(max_bs, 1, dtype=torch.long, device=dev)
+        positions = torch.zeros(max_bs, 1, dtype=torch.long, device=dev)
+        slots = torch.full((max_bs, 1), _PAD_SLOT_ID, dtype=torch.long, device=dev)
+        context_lens = torch.ones(max_bs, dtype=torch.int32, device=dev)
+        block_tables = torch.zeros(max_bs, max_blocks, dtype=torch.int32, device=dev)
+        limit = min(max_bs, _get_graph_batch_size(self.scheduler_config.max_num_seqs))
+        for bs in reversed([b for b in _BATCH_SIZES_TO_CAPTURE if b <= limit]):
+            md = InputMetadata(is_prompt=False, slot_mapping=slots[:bs], prompt_lens=None, max_seq_len=None,
+                               start_loc=None, max_context_len=self.max_context_len_to_capture,
+                               context_lens=context_lens[:bs], block_tables=block_tables[:bs],
+                               use_cuda_graph=True, kv_cache_dtype=self.kv_cache_dtype)
+            runner = HIPGraphRunner(self.model)
+            runner.capture(tokens[:bs], positions[:bs], kv_caches, md, self.graph_memory_pool)
+            self.graph_memory_pool = runner.graph.pool()
+            self.graph_runners[bs] = runner
+        self.capture_seconds = time.perf_counter() - t0
+
+
+class HIPGraphRunner:
+    """One captured decode step: static input buffers, graph replay, static output."""
+
+    def __init__(self, model) -> None:
+        self.model = model
+        self.graph: Optional[torch.cuda.CUDAGraph] = None
+        self.inputs: Dict[str, torch.Tensor] = {}
+        self.output: Optional[torch.Tensor] = None
+
+    def capture(self, tokens, positions, kv_caches, md: InputMetadata, pool) -> None:
+        assert self.graph is None
+        # warm-up run outside the capture (lazy initialisation inside libraries)
+        self.model(tokens.view(-1), positions.view(-1), kv_caches, md)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, pool=pool):
+            hidden = self.model(tokens.view(-1), positions.view(-1), kv_caches, md)
+        torch.cuda.synchronize()
+        self.inputs = {"tokens": tokens, "positions": positions, "slot_mapping": md.slot_mapping,
+                       "context_lens": md.context_lens, "block_tables": md.block_tables}
+        self.output = hidden
+
+    def __call__(self, tokens, positions, kv_caches, md: InputMetadata) -> torch.Tensor:
+        del kv_caches                                   # baked into the graph
+        self.inputs["tokens"].copy_(tokens, non_blocking=True)
+        self.inputs["positions"].copy_(positions, non_blocking=True)
+        self.inputs["slot_mapping"].copy_(md.slot_mapping, non_blocking=True)
+        self.inputs["context_lens"].copy_(md.context_lens, non_blocking=True)
+        self.inputs["block_tables"].copy_(md.block_tables, non_blocking=True)
+        self.graph.replay()
+        return self.output

@@ -1,0 +1,235 @@
+"""One worker per GPU: owns the model replica (or TP shard), the KV cache and the KV transport.
+
+Method names and the step contract follow vllm/worker/worker.py:35-403:
+  * worker kinds: MIXED (co-located), PROMPT (first half of the world), TOKEN (second half);
+    rank r of the prompt pool is paired with rank r + num_prompt_workers (:126-144);
+  * execute_model (:271-334): cache swap / copy first; a TOKEN worker then waits on the hand-off
+    slot of every sequence in ``blocks_to_nw`` before its first decode step; the model runs (a
+    PROMPT worker pushes each layer's blocks from inside the attention layers); a PROMPT worker
+    finally signals every slot, ordered after all layers' pushes.
+"""
+import enum
+import gc
+import os
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+from ..config import CacheConfig, DeviceConfig, ModelConfig, ParallelConfig, SchedulerConfig
+from ..model_executor import parallel_state
+from ..sequence import SamplerOutput, SequenceGroupMetadata
+from .cache_engine import CacheEngine
+from .model_runner import ModelRunner
+
+
+class WorkerType(enum.Enum):
+    PROMPT = enum.auto()
+    TOKEN = enum.auto()
+    MIXED = enum.auto()
+
+
+class Worker:
+    def __init__(self, model_config: ModelConfig, parallel_config: ParallelConfig,
+                 scheduler_config: SchedulerConfig, device_config: DeviceConfig, local_rank: int = 0,
+                 rank: int = 0, distributed_init_method: Optional[str] = None, kv_cache_dtype: str = "auto",
+                 is_driver_worker: bool = True, kv_transport_init: Optional[dict] = None) -> None:
+        self.model_config = model_config
+        self.parallel_config = parallel_config
+        self.scheduler_config = scheduler_config
+        self.device_config = device_config
+        self.local_rank = local_rank
+        self.rank = rank
+        self.distributed_init_method = distributed_init_method
+        self.is_driver_worker = is_driver_worker
+        self.kv_transport_init = kv_transport_init
+        self.model_runner = ModelRunner(model_config, parallel_config, scheduler_config, device_config,
+                                        kv_cache_dtype=kv_cache_dtype, is_driver_worker=is_driver_worker)
+        self.cache_config: Optional[CacheConfig] = None
+        self.cache_engine: Optional[CacheEngine] = None
+        self.gpu_cache = None
+        self.kvcache_comm_manager = None
+        self.worker_type = WorkerType.MIXED
+        self.device: Optional[torch.device] = None
+        self.init_gpu_memory = 0
+
+    def is_prompt_worker(self) -> bool:
+        return self.worker_type == WorkerType.PROMPT
+
+    def is_token_worker(self) -> bool:
+        return self.worker_type == WorkerType.TOKEN
+
+    def is_mixed_worker(self) -> bool:
+        return self.worker_type == WorkerType.MIXED
+
+    # ------------------------------------------------------------------ set-up
+    def init_model(self) -> None:
+        if self.device_config.device.type != "cuda":
+            raise RuntimeError(f"Not support device type: {self.device_config.device}")
+        self.device = torch.device(f"cuda:{self.local_rank}")
+        torch.cuda.set_device(self.device)
+        self.model_runner.device = self.device
+        torch.cuda.empty_cache()
+        self.init_gpu_memory = torch.cuda.mem_get_info()[0]
+        if self.parallel_config.world_size > 1 and not dist.is_initialized():
+            if not self.distributed_init_method:
+                raise ValueError("distributed_init_method must be set if torch.distributed is not already "
+                                 "initialized")
+            dist.init_process_group(backend="nccl", world_size=self.parallel_config.world_size, rank=self.rank,
+                                    init_method=self.distributed_init_method)
+        if dist.is_initialized() and self.parallel_config.tensor_parallel_size > 1:
+            dist.all_reduce(torch.zeros(1, device=self.device))       # warm-up (worker.py:452-455)
+        parallel_state.initialize_model_parallel(self.parallel_config.tensor_parallel_size,
+                                                 self.parallel_config.sep_prompt_token)
+        self.init_kvcache_comm(self.kv_transport_init)
+        torch.manual_seed(self.model_config.seed)
+
+    def init_kvcache_comm(self, kv_transport_init: Optional[dict] = None) -> None:
+        if kv_transport_init is None:
+            return
+        from .kv_comm import KVCacheCommManager
+        n = self.parallel_config.num_prompt_workers
+        self.kvcache_comm_manager = KVCacheCommManager(self.rank, self.parallel_config.world_size, n,
+                                                       kv_transport_init)
+        self.worker_type = WorkerType.PROMPT if self.rank < n else WorkerType.TOKEN
+        # the first rank of each pool drives it (worker.py:138-144)
+        self.model_runner.driver_rank = (self.rank // n) * n
+        if self.rank == self.model_runner.driver_rank:
+            self.is_driver_worker = True
+            self.model_runner.is_driver_worker = True
+
+    def load_model(self) -> None:
+        self.model_runner.load_model()
+
+    @torch.inference_mode()
+    def profile_num_available_blocks(self, block_size: int, gpu_memory_utilization: float, cpu_swap_space: int,
+                                     cache_dtype: str) -> Tuple[int, int]:
+        """Blocks that fit beside the weights and the peak activations (worker.py:180-227)."""
+        torch.cuda.empty_cache()
+        torch.cuda.reset_peak_memory_stats()
+        self.model_runner.profile_run()
+        torch.cuda.synchronize()
+        free_gpu_memory, total_gpu_memory = torch.cuda.mem_get_info()
+        peak_memory = self.init_gpu_memory - free_gpu_memory
+        cache_block_size = self.get_cache_block_size_bytes(block_size, cache_dtype)
+        num_gpu_blocks = int((total_gpu_memory * gpu_memory_utilization - peak_memory) // cache_block_size)
+        num_cpu_blocks = int(cpu_swap_space // cache_block_size)
+        gc.collect()
+        torch.cuda.empty_cache()
+        return max(num_gpu_blocks, 0), max(num_cpu_blocks, 0)
+
+    def init_cache_engine(self, cache_config: CacheConfig) -> None:
+        self.cache_config = cache_config
+        self.cache_engine = CacheEngine(cache_config, self.model_config, self.parallel_config, self.device)
+        self.gpu_cache = self.cache_engine.gpu_cache
+        self.model_runner.set_block_size(self.cache_engine.block_size)
+
+    def warm_up_model(self) -> None:
+        if not self.model_config.enforce_eager:
+            self.model_runner.capture_model(self.gpu_cache)
+        torch.manual_seed(self.model_config.seed)
+
+    def setup_kvcache_comm(self) -> None:
+        if self.kvcache_comm_manager is None:
+            return
+        num_layers = self.model_config.get_num_layers(self.parallel_config)
+        self.kvcache_comm_manager.setup_comm(num_layers, self.gpu_cache)
+        self.set_comm_for_attention_modules()
+
+    def destroy_kvcache_comm(self) -> None:
+        if self.kvcache_comm_manager is not None:
+            self.kvcache_comm_manager.destroy_comm()
+            for module in self._attention_modules():
+                module.kvcache_comm_manager = None
+
+    def _attention_modules(self):
+        return [m for m in self.model_runner.model.modules() if m.__class__.__name__ == "Attention"]
+
+    def set_comm_for_attention_modules(self) -> None:
+        for i, module in enumerate(self._attention_modules()):
+            module.set_kvcache_comm_manager(self.kvcache_comm_manager)
+            module.layer_id = i
+
+    # -------------------------------------------------------------------- step
+    def cache_swap(self, blocks_to_swap_in: Dict[int, int], blocks_to_swap_out: Dict[int, int],
+                   blocks_to_copy: Dict[int, List[int]]) -> None:
+        issued = False
+        if blocks_to_swap_in:
+            self.cache_engine.swap_in(blocks_to_swap_in)
+            issued = True
+        if blocks_to_swap_out:
+            self.cache_engine.swap_out(blocks_to_swap_out)
+            issued = True
+        if issued:
+            for event in self.cache_engine.events:
+                event.wait()                      # the compute stream waits, the host does not
+        if blocks_to_copy:
+            self.cache_engine.copy(blocks_to_copy)
+
+    def should_execute(self, is_prompt: bool) -> bool:
+        return (self.is_mixed_worker() or (self.is_prompt_worker() and is_prompt)
+                or (self.is_token_worker() and not is_prompt))
+
+    @torch.inference_mode()
+    def execute_model(self, seq_group_metadata_list: Optional[List[SequenceGroupMetadata]] = None,
+                      blocks_to_swap_in: Optional[Dict[int, int]] = None,
+                      blocks_to_swap_out: Optional[Dict[int, int]] = None,
+                      blocks_to_copy: Optional[Dict[int, List[int]]] = None,
+                      blocks_to_nw: Optional[Dict[int, List[Tuple[int, int]]]] = None) -> Optional[SamplerOutput]:
+        blocks_to_nw = blocks_to_nw or {}
+        self.cache_swap(blocks_to_swap_in or {}, blocks_to_swap_out or {}, blocks_to_copy or {})
+        if not seq_group_metadata_list:
+            return SamplerOutput([])
+        is_prompt = seq_group_metadata_list[0].is_prompt
+        comm = self.kvcache_comm_manager
+        if blocks_to_nw and comm is not None and self.is_token_worker() and not is_prompt:
+            for sem_id in blocks_to_nw:
+                comm.wait(sem_id)
+        output = self.model_runner.execute_model(seq_group_metadata_list, self.gpu_cache, blocks_to_nw)
+        if blocks_to_nw and comm is not None and self.is_prompt_worker() and is_prompt:
+            for sem_id in blocks_to_nw:
+                comm.signal_and_flush(sem_id)
+        return output
+
+    # ------------------------------------------- transport self-test (worker.py:350-386)
+    def set_gpucache(self) -> None:
+        num_layers = self.model_config.get_num_layers(self.parallel_config)
+        for layer in range(num_layers):
+            for t in (0, 1):
+                self.gpu_cache[layer][t].fill_(self.rank * (num_layers * 2) + layer * 2 + t)
+        torch.cuda.synchronize()
+
+    def send_recv_kvcache_all(self) -> None:
+        if self.kvcache_comm_manager is None:
+            return
+        num_layers = self.model_config.get_num_layers(self.parallel_config)
+        if self.rank < self.parallel_config.num_prompt_workers:
+            for layer in range(num_layers):
+                self.kvcache_comm_manager.put(0, layer, 0, self.cache_config.num_gpu_blocks)
+            self.kvcache_comm_manager.signal_and_flush(0)
+        else:
+            self.kvcache_comm_manager.wait(0)
+        torch.cuda.synchronize()
+
+    def check_gpucache(self) -> None:
+        if self.kvcache_comm_manager is None:
+            return
+        n = self.parallel_config.num_prompt_workers
+        num_layers = self.model_config.get_num_layers(self.parallel_config)
+        src = self.rank if self.rank < n else self.rank - n
+        for layer in range(num_layers):
+            for t in (0, 1):
+                expected = src * (num_layers * 2) + layer * 2 + t
+                cache = self.gpu_cache[layer][t]
+                assert torch.all(cache.float() == float(expected)), (layer, t, expected)
+
+    @property
+    def max_model_len(self) -> int:
+        return self.model_config.max_model_len
+
+    @property
+    def vocab_size(self) -> int:
+        return self.model_runner.vocab_size
+
+    def get_cache_block_size_bytes(self, block_size: int, cache_dtype: str) -> int:
+        return CacheEngine.get_cache_block_size(block_size, cache_dtype, self.model_config, self.parallel_config)
