@@ -316,6 +316,8 @@ def _rows(t: torch.Tensor):
 def rms_norm(out: torch.Tensor, input: torch.Tensor, weight: torch.Tensor, epsilon: float) -> None:
     """``ops.rms_norm`` (csrc/layernorm_kernels.cu:70-92)."""
     _require_cuda(out, input, weight)
+    if weight.dtype != input.dtype or out.dtype != input.dtype:
+        raise RuntimeError("rms_norm: out, input and weight must share one dtype")
     rows, stride = _rows(input)
     if not out.is_contiguous():
         raise RuntimeError("rms_norm: out must be contiguous")
@@ -328,6 +330,8 @@ def fused_add_rms_norm(input: torch.Tensor, residual: torch.Tensor, weight: torc
                        epsilon: float) -> None:
     """``ops.fused_add_rms_norm`` (csrc/layernorm_kernels.cu:94-118), in place on both."""
     _require_cuda(input, residual, weight)
+    if weight.dtype != input.dtype or residual.dtype != input.dtype:
+        raise RuntimeError("fused_add_rms_norm: input, residual and weight must share one dtype")
     rows, stride = _rows(input)
     if not residual.is_contiguous():
         raise RuntimeError("fused_add_rms_norm: residual must be contiguous")

@@ -54,8 +54,15 @@ def _random_init(model: nn.Module, seed: int) -> None:
 
 def get_model(model_config: ModelConfig, device: torch.device) -> nn.Module:
     cls = _ARCH[model_config.architecture]
-    with torch.device(device):
-        model = cls(model_config.hf_config, model_config.dtype, _linear_method(model_config))
+    # parameters created without an explicit dtype (norm weights) take the model dtype
+    # (vllm/model_executor/model_loader.py:24-31 sets the default dtype the same way)
+    old_dtype = torch.get_default_dtype()
+    torch.set_default_dtype(model_config.dtype)
+    try:
+        with torch.device(device):
+            model = cls(model_config.hf_config, model_config.dtype, _linear_method(model_config))
+    finally:
+        torch.set_default_dtype(old_dtype)
     files = sorted(glob.glob(os.path.join(model_config.model, "*.safetensors"))) if os.path.isdir(
         model_config.model) else []
     if files:
