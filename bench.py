@@ -1,0 +1,288 @@
+#!/usr/bin/env python3
+"""Headline benchmark: goodput (tok/s under a TTFT + TBT SLO) of Llama-2-7B serving.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+N = 1  co-located serving on one MI355X (the configuration the metric is quoted on).
+N > 1  N/2 independent (prompt GPU, token GPU) pairs: every pair runs the split path with
+       the KV blocks of each prompt pushed prefill -> decode over xGMI; requests are
+       independent, so pairs share nothing (weak scaling, no data-path collective).
+
+A *step* is one engine iteration: one scheduling decision plus one pass of the hot path
+(a prompt batch or a decode batch) on the GPU.  The workload is closed-loop: C requests are
+kept in flight (a finished request is replaced at once), each with a 772-token synthetic
+prompt and 170 generated tokens -- the mean request shape of the reference's own benchmark
+logs.  Goodput counts the tokens generated inside the timed region by requests that meet
+the reference's SLO (TTFT <= 0.25 s and mean time between tokens <= 0.1 s).
+
+The JSON line also carries
+  roofline      decode paged attention (the dominant, HBM-bound kernel): algorithmic KV bytes
+                per launch / average launch time, timed with HIP events on the launch stream
+                over decode batches sampled from the timed region;
+  cpu_baseline  the CPU oracle (torch restatement of the same model and operators) timed on the
+                host cores on a bounded sample, scaled to tok/s.
+"""
+import argparse
+import json
+import os
+import random
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "vllm-splitwise_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import torch  # noqa: E402
+
+PROMPT_LEN = 772
+DECODE_LEN = 170
+SLO_TTFT = 0.25
+SLO_TPOT = 0.10
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=600)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--concurrency", type=int, default=128, help="requests kept in flight per replica")
+    ap.add_argument("--model", default="llama-2-7b")
+    ap.add_argument("--prompt-len", type=int, default=PROMPT_LEN)
+    ap.add_argument("--decode-len", type=int, default=DECODE_LEN)
+    ap.add_argument("--max-num-batched-tokens", type=int, default=4096)
+    ap.add_argument("--enforce-eager", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+class ClosedLoop:
+    """Keeps `concurrency` requests in flight; records a timestamp per generated token."""
+
+    def __init__(self, engine, concurrency, prompt_len, decode_len, seed):
+        from splitwise_amd import SamplingParams
+        self.engine = engine
+        self.concurrency = concurrency
+        self.prompt_len = prompt_len
+        self.rng = random.Random(seed)
+        self.vocab = engine.model_config.get_vocab_size()
+        self.params = SamplingParams(temperature=0.0, max_tokens=decode_len, ignore_eos=True)
+        self.next_id = 0
+        self.live = 0
+        self.ramp = 0
+        self.req = {}                # request id -> dict(arrival, first, last, n, window_tokens)
+        self.step_kinds = {True: [0, 0.0], False: [0, 0.0]}     # prompt_run -> [steps, seconds] in window
+
+    def _add(self, now):
+        from splitwise_amd import SamplingParams
+        rid = str(self.next_id)
+        self.next_id += 1
+        prompt = [self.rng.randrange(self.vocab) for _ in range(self.prompt_len)]
+        params = self.params
+        if self.next_id <= self.concurrency:
+            # the first cohort gets random lengths so that completions (and hence prompt arrivals)
+            # are spread over time instead of coming in one burst every `decode_len` steps
+            params = SamplingParams(temperature=0.0, max_tokens=self.rng.randint(1, self.params.max_tokens),
+                                    ignore_eos=True)
+        self.engine.add_request(rid, None, params, prompt_token_ids=prompt)
+        self.req[rid] = dict(arrival=now, first=None, last=None, n=0, window=0)
+        self.live += 1
+
+    def feed(self):
+        """One new request per step while ramping up (so no request queues behind a burst),
+        then one per finished request."""
+        now = time.perf_counter()
+        if self.ramp < self.concurrency:
+            self.ramp += 1
+            self._add(now)
+        while self.live < min(self.ramp, self.concurrency):
+            self._add(now)
+
+    def step(self, in_window):
+        self.feed()
+        t_begin = time.perf_counter()
+        had_waiting = bool(self.engine.scheduler.waiting)
+        outs = self.engine.step()
+        now = time.perf_counter()
+        if in_window:
+            kind = self.step_kinds[had_waiting]
+            kind[0] += 1
+            kind[1] += now - t_begin
+        new_tokens = 0
+        for out in outs:
+            r = self.req[out.request_id]
+            n = len(out.outputs[0].token_ids)
+            if n > r["n"]:
+                new_tokens += n - r["n"]
+                if in_window:
+                    r["window"] += n - r["n"]
+                r["n"] = n
+                if r["first"] is None:
+                    r["first"] = now
+                r["last"] = now
+            if out.finished:
+                self.live -= 1
+        return new_tokens
+
+    def goodput_tokens(self):
+        good = total = 0
+        met = seen = 0
+        ttfts, tpots = [], []
+        for r in self.req.values():
+            if r["window"] == 0 or r["first"] is None:
+                continue
+            ttft = r["first"] - r["arrival"]
+            tpot = (r["last"] - r["first"]) / (r["n"] - 1) if r["n"] > 1 else 0.0
+            ok = ttft <= SLO_TTFT and tpot <= SLO_TPOT
+            total += r["window"]
+            good += r["window"] if ok else 0
+            seen += 1
+            met += ok
+            ttfts.append(ttft)
+            tpots.append(tpot)
+        return good, total, met, seen, ttfts, tpots
+
+
+def measure_attention_roofline(engine, samples):
+    """Average launch time of the decode paged-attention kernel over the sampled decode batches
+    (block tables / context lengths taken from the timed region), timed with HIP events on the
+    stream the kernel is launched on."""
+    from splitwise_amd.model_executor.layers.attention import PagedAttentionImpl
+    worker = engine.model_executor.driver_worker
+    cfg = engine.model_config
+    par = engine.parallel_config
+    h = cfg.hf_config["num_attention_heads"] // par.tensor_parallel_size
+    kvh = cfg.get_num_kv_heads(par)
+    d = cfg.get_head_size()
+    es = torch.tensor([], dtype=worker.gpu_cache[0][0].dtype).element_size()
+    scale = d ** -0.5
+    dev = worker.device
+    stream = torch.cuda.current_stream(dev)
+    total_ms, launches, alg_bytes = 0.0, 0, 0.0
+    layers = worker.gpu_cache
+    for md in samples:
+        n = md.context_lens.numel()
+        q = torch.empty(n, h, d, dtype=cfg.dtype, device=dev).uniform_(-scale, scale)
+        ctx_sum = int(md.context_lens.sum().item())
+        per_launch = 2.0 * ctx_sum * kvh * d * es + 2.0 * n * h * d * q.element_size() + md.block_tables.numel() * 4
+        for kc, vc in layers[:2]:                  # warm the code path
+            PagedAttentionImpl.forward_decode(q, kc, vc, md, kvh, scale, None)
+        start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        start.record(stream)
+        for kc, vc in layers:                      # one launch per layer, each over its own cache
+            PagedAttentionImpl.forward_decode(q, kc, vc, md, kvh, scale, None)
+        end.record(stream)
+        end.synchronize()
+        total_ms += start.elapsed_time(end)
+        launches += len(layers)
+        alg_bytes += per_launch * len(layers)
+    if launches == 0:
+        return None
+    avg_s = total_ms * 1e-3 / launches
+    achieved = alg_bytes / launches / avg_s / 1e9
+    return {"bound": "hbm", "kernel": "paged_attention_kernel (decode)", "achieved": round(achieved, 1),
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            "avg_launch_us": round(avg_s * 1e6, 2), "launches_timed": launches,
+            "alg_bytes_per_launch": int(alg_bytes / launches)}
+
+
+def cpu_baseline(model_name, prompt_len, decode_len):
+    """The CPU oracle on a bounded sample of the same workload, scaled to tok/s."""
+    from oracle import serving as oserving
+    threads = torch.get_num_threads()
+    res = oserving.timed_sample(model_name, prompt_len=prompt_len, decode_len=decode_len, layers=2,
+                                num_requests=2, decode_steps=4, budget_s=25.0)
+    return {"value": round(res["tokens_per_s"], 3), "unit": "tok/s", "cores": threads, "kind": "port",
+            "sample": res["sample"]}
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 or world > 1:
+        from splitwise_amd.executor import bench_split
+        return bench_split.run(args, rank, local_rank, world)
+
+    from splitwise_amd import EngineArgs, LLMEngine
+    torch.cuda.set_device(0)
+    conc = args.concurrency
+    warmup = args.warmup if args.warmup is not None else 3 * conc
+    seq_blocks = -(-(args.prompt_len + args.decode_len + 1) // 16)
+    engine = LLMEngine.from_engine_args(EngineArgs(
+        model=args.model, max_num_seqs=conc, max_model_len=2048, max_num_batched_tokens=args.max_num_batched_tokens,
+        num_gpu_blocks_override=int(conc * seq_blocks * 1.25) + 64, swap_space=0.25,
+        enforce_eager=args.enforce_eager, max_context_len_to_capture=1024))
+    loop = ClosedLoop(engine, conc, args.prompt_len, args.decode_len, seed=0)
+
+    # sample decode batches of the timed region for the roofline measurement (references only)
+    runner = engine.model_executor.driver_worker.model_runner
+    samples = []
+    orig_prepare = runner._prepare_decode
+    state = {"on": False, "count": 0}
+
+    def sampling_prepare(metas):
+        out = orig_prepare(metas)
+        if state["on"]:
+            state["count"] += 1
+            if state["count"] % 16 == 1 and len(samples) < 12:
+                md = out[2]
+                n = sum(len(m.seq_data) for m in metas)
+                import copy
+                keep = copy.copy(md)
+                keep.context_lens = md.context_lens[:n].clone()
+                keep.block_tables = md.block_tables[:n].clone()
+                keep.max_context_len = md.max_context_len
+                samples.append(keep)
+        return out
+
+    runner._prepare_decode = sampling_prepare
+
+    for _ in range(warmup):
+        loop.step(False)
+    torch.cuda.synchronize()
+    state["on"] = True
+    t0 = time.perf_counter()
+    tokens = 0
+    for _ in range(args.steps):
+        tokens += loop.step(True)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    state["on"] = False
+
+    good, total, met, seen, ttfts, tpots = loop.goodput_tokens()
+    result = {
+        "metric": "goodput (tok/s under TTFT+TBT SLO), Llama-2-7B co-located", "value": round(good / elapsed, 2),
+        "unit": "tok/s", "n_gpus": 1, "steps": args.steps, "warmup": warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"{args.model} bf16 co-located on 1 GPU, closed loop with {conc} requests in flight, "
+                               f"prefill {args.prompt_len} / decode {args.decode_len} tokens, random-init weights, "
+                               f"SLO TTFT<={SLO_TTFT}s TPOT<={SLO_TPOT}s",
+                   "concurrency": conc, "prompt_len": args.prompt_len, "decode_len": args.decode_len,
+                   "hip_graphs": not args.enforce_eager},
+        "throughput_tok_s": round(total / elapsed, 2),
+        "slo_attainment": round(met / max(seen, 1), 4),
+        "prompt_steps": loop.step_kinds[True][0],
+        "avg_prompt_step_ms": round(loop.step_kinds[True][1] / max(loop.step_kinds[True][0], 1) * 1e3, 2),
+        "decode_steps": loop.step_kinds[False][0],
+        "avg_decode_step_ms": round(loop.step_kinds[False][1] / max(loop.step_kinds[False][0], 1) * 1e3, 2),
+        "ttft_p50_ms": round(sorted(ttfts)[len(ttfts) // 2] * 1e3, 2) if ttfts else None,
+        "ttft_p99_ms": round(sorted(ttfts)[int(len(ttfts) * 0.99)] * 1e3, 2) if ttfts else None,
+        "tpot_p50_ms": round(sorted(tpots)[len(tpots) // 2] * 1e3, 2) if tpots else None,
+        "tpot_p99_ms": round(sorted(tpots)[int(len(tpots) * 0.99)] * 1e3, 2) if tpots else None,
+    }
+    if not args.no_roofline:
+        result["roofline"] = measure_attention_roofline(engine, samples)
+    if not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(args.model, args.prompt_len, args.decode_len)
+    print(json.dumps(result))
+
+
+if __name__ == "__main__":
+    main()
