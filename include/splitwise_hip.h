@@ -145,6 +145,35 @@ int sw_prefill_attention(void* out, const void* query, const void* key,
                          int64_t k_stride, int64_t v_stride, int64_t out_stride,
                          int sliding_window, int act_dtype, void* stream);
 
+/* --------------------------------------------------------------- KV transport
+ * Replaces the reference's MSCCL++ proxy-channel kernels (csrc/kv_comm_kernels.cu:3-29) and
+ * the memory registration of vllm/worker/comm_utils.py:171-207.
+ *
+ * sw_ipc_*: export a device allocation to / map it from another process on this node
+ * (HIP IPC; peer GPUs are reached over xGMI).  A handle is 64 opaque bytes.            */
+int sw_ipc_get_mem_handle(const void* dev_ptr, void* handle_out64);
+int sw_ipc_open_mem_handle(const void* handle64, void** dev_ptr_out);
+int sw_ipc_close_mem_handle(void* dev_ptr);
+
+/* nw_cache_out_kernel / KVCacheCommunicator.put (comm_utils.py:132-147): copy num_runs byte
+ * ranges src_base + offsets[i] -> dst_base + offsets[i] (same offset on both sides), each
+ * nbytes[i] long; offsets and sizes are HOST arrays and multiples of 16.  dst_base is normally
+ * the IPC mapping of the peer worker's cache.  Stream-ordered, non-blocking on the host.  */
+int sw_kv_push(void* dst_base, const void* src_base, const int64_t* offsets,
+               const int64_t* nbytes, int num_runs, void* stream);
+
+/* nw_cache_out_signal_kernel (kv_comm_kernels.cu:22-29): after a system-scope release,
+ * flags[slot] := epoch in the PEER's flag array (IPC mapping).  Ordered after every earlier
+ * sw_kv_push on the same stream.                                                         */
+int sw_kv_signal(int32_t* flags, int slot, int32_t epoch, void* stream);
+
+/* nw_cache_in_kernel (kv_comm_kernels.cu:3-9): wait on the stream until the LOCAL
+ * flags[slot] has reached epoch, at most max_spins polls (the reference bounds its wait at
+ * 1e8 spins); on a timeout *status (device or pinned-host word) := 1 + slot and the stream
+ * continues.                                                                              */
+int sw_kv_wait(const int32_t* flags, int slot, int32_t epoch, int64_t max_spins,
+               int32_t* status, void* stream);
+
 /* -------------------------------------------- row-wise operators beside the path
  * csrc/layernorm_kernels.cu:70-118 rms_norm / fused_add_rms_norm.
  *   out = (act)(x * rsqrt(mean(x^2) + eps)) * weight, per row of hidden_size elements.

@@ -1,0 +1,126 @@
+"""GPU parity: the KV transport (push / signal / wait through the C ABI) and the split
+prompt-pool / token-pool engine.
+
+Known-answer pattern of the reference's transport test (tests/distributed/test_kvcache_comm.py
+:28-42 with vllm/worker/worker.py:350-386): the sender's cache holds a constant per (rank,
+layer, tensor); after put + signal / wait the receiver must hold the sender's constants.  Here
+it is also checked for arbitrary (block_start, num_blocks) runs: bytes inside the runs equal
+the source, everything else is untouched (bit-exact).  Both workers share the one GPU of the
+test box; the IPC mapping, the kernels and the flag protocol are the same as across two GPUs.
+"""
+import random
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_push_runs_bit_exact_and_rest_untouched():
+    from splitwise_amd import _C
+    torch.manual_seed(0)
+    nbytes = 3 * 1024 * 1024 + 4096
+    src = torch.randint(0, 256, (nbytes,), dtype=torch.uint8, device="cuda")
+    dst = torch.randint(0, 256, (nbytes,), dtype=torch.uint8, device="cuda")
+    before = dst.clone()
+    # ragged runs: tiny, odd multiples of 16, larger than one 64-KiB chunk, adjacent runs
+    runs = [(0, 16), (4096, 48), (65536, 65536 * 3 + 32), (1048576, 16), (1048592, 131072), (nbytes - 160, 160)]
+    _C.kv_ops.kv_push(dst.data_ptr(), src.data_ptr(), [o for o, _ in runs], [n for _, n in runs],
+                      torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    expect = before.clone()
+    for off, n in runs:
+        expect[off:off + n] = src[off:off + n]
+    assert torch.equal(dst, expect)
+    # more runs than one launch carries
+    many = [(i * 4096, 16 * (1 + i % 5)) for i in range(130)]
+    dst2 = before.clone()
+    _C.kv_ops.kv_push(dst2.data_ptr(), src.data_ptr(), [o for o, _ in many], [n for _, n in many],
+                      torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    expect = before.clone()
+    for off, n in many:
+        expect[off:off + n] = src[off:off + n]
+    assert torch.equal(dst2, expect)
+    with pytest.raises(RuntimeError, match="16-byte"):
+        _C.kv_ops.kv_push(dst.data_ptr(), src.data_ptr(), [8], [16], 0)
+    _C.kv_ops.kv_push(dst.data_ptr(), src.data_ptr(), [], [], 0)          # empty: no-op
+
+
+def test_signal_then_wait_and_timeout():
+    from splitwise_amd import _C
+    flags = torch.zeros(260, dtype=torch.int32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    status_ptr = flags.data_ptr() + 4 * 256
+    _C.kv_ops.kv_signal(flags.data_ptr(), 7, 1, stream)
+    _C.kv_ops.kv_wait(flags.data_ptr(), 7, 1, 1000, status_ptr, stream)
+    torch.cuda.synchronize()
+    assert flags[7].item() == 1 and flags[256].item() == 0
+    # epochs only grow: a later epoch satisfies an earlier wait
+    _C.kv_ops.kv_signal(flags.data_ptr(), 7, 3, stream)
+    _C.kv_ops.kv_wait(flags.data_ptr(), 7, 2, 1000, status_ptr, stream)
+    torch.cuda.synchronize()
+    assert flags[256].item() == 0
+    # nobody signals slot 9: the bounded wait gives up and reports the slot
+    _C.kv_ops.kv_wait(flags.data_ptr(), 9, 1, 2000, status_ptr, stream)
+    torch.cuda.synchronize()
+    assert flags[256].item() == 10
+
+
+def _split_llm(transport, **kw):
+    from splitwise_amd import LLM
+    return LLM("llama-tiny", sep_prompt_token=True, enforce_eager=False, num_gpu_blocks_override=192,
+               max_num_seqs=8, max_model_len=512, swap_space=0.01, **kw)
+
+
+@pytest.mark.parametrize("transport", ["kernel", "runtime"])
+def test_transport_self_test_between_two_processes(transport):
+    """set_gpucache / send_recv_kvcache_all / check_gpucache of the reference, both transports."""
+    from splitwise_amd.engine.arg_utils import EngineArgs
+    from splitwise_amd.executor.splitwise_executor import SplitwiseExecutor
+    args = EngineArgs(model="llama-tiny", sep_prompt_token=True, enforce_eager=True, num_gpu_blocks_override=64,
+                      max_num_seqs=4, max_model_len=256, swap_space=0.01)
+    mc, cc, pc, sc, dc = args.create_engine_configs()
+    ex = SplitwiseExecutor(mc, cc, pc, sc, dc, num_gpu_blocks_override=64, prompt_device=0, token_device=0,
+                           transport=transport)
+    try:
+        ex._remote_call("set_gpucache")
+        ex.driver_worker.set_gpucache()
+        ex._remote_async("send_recv_kvcache_all")
+        ex.driver_worker.send_recv_kvcache_all()
+        ex._remote_wait()
+        ex._remote_call("check_gpucache")          # raises in the token worker on a mismatch
+        ex.driver_worker.check_gpucache()
+        assert ex.kv_bytes_pushed() == 2 * mc.hf_config["num_hidden_layers"] * 64 * 16 * 2 * 64 * 2
+    finally:
+        ex.shutdown()
+
+
+@pytest.mark.parametrize("overlap", [True, False])
+def test_split_engine_generates_like_the_cpu_model(overlap):
+    """1 prompt worker + 1 token worker (two processes): every decode step runs on KV that was
+    pushed from the prompt worker; greedy tokens must agree with the whole-model CPU oracle."""
+    from splitwise_amd import SamplingParams
+    from oracle import model as omodel
+    random.seed(0)
+    llm = _split_llm("kernel")
+    try:
+        llm.llm_engine.overlap_pools = overlap
+        prompts = [[random.randrange(512) for _ in range(n)] for n in (5, 33, 64, 17, 100, 1, 16, 48, 7, 90, 31)]
+        outs = llm.generate(prompt_token_ids=prompts, sampling_params=SamplingParams(temperature=0.0, max_tokens=20))
+        assert all(len(o.outputs[0].token_ids) == 20 for o in outs)
+        runner = llm.llm_engine.model_executor.driver_worker.model_runner
+        sd = {k: v.detach().cpu() for k, v in runner.model.state_dict().items()}
+        cfg = runner.model_config.hf_config
+        for prompt, out in zip(prompts, outs):
+            gen = out.outputs[0].token_ids
+            ref = omodel.logits("llama", sd, cfg, prompt + gen)
+            for j, tok in enumerate(gen):
+                row = ref[len(prompt) + j - 1]
+                assert row[tok] >= row.max() - 3e-2, (j, tok, int(row.argmax()))
+        pushed = llm.llm_engine.model_executor.kv_bytes_pushed()
+        blocks = sum(-(-len(p) // 16) for p in prompts)
+        assert pushed == blocks * 2 * cfg["num_hidden_layers"] * 16 * 2 * 64 * 2      # K+V, bf16... f16 blocks
+        llm.llm_engine.model_executor.driver_worker.kvcache_comm_manager.check_status()
+    finally:
+        llm.llm_engine.model_executor.shutdown()

@@ -1,0 +1,161 @@
+// KV-block transport between a prompt worker and its token worker (Splitwise hand-off).
+//
+// What it replaces: the reference's three one-thread kernels that enqueue put / signal / wait
+// requests into an MSCCL++ proxy FIFO served by a CPU thread (csrc/kv_comm_kernels.cu:3-29,
+// vllm/worker/comm_utils.py:90-147).  Here the GPU moves the bytes itself: the token
+// worker's cache is mapped into the prompt worker's address space (HIP IPC over xGMI) and
+//   * sw_kv_push   copies byte ranges local cache -> peer cache, same offset on both sides
+//                  (comm_utils.py:132-147), 16 bytes per lane, any number of ranges per launch;
+//   * sw_kv_signal publishes a per-sequence hand-off flag in the peer's memory after a
+//                  system-scope release (ordered after every earlier push on the stream);
+//   * sw_kv_wait   spins (bounded, like the reference's 1e8 bound) on the local flag with
+//                  system-scope loads, then acquires, so later kernels read the pushed KV.
+// Flags carry an epoch (hand-off count of the slot), never reset, so a slot is reusable
+// without a clearing step.
+#include "common.cuh"
+
+#include <algorithm>
+#include <string.h>
+
+namespace sw {
+
+constexpr int kMaxRuns = 48;
+constexpr int kPushThreads = 256;
+constexpr int64_t kChunkBytes = 64 * 1024;          // bytes one workgroup moves
+
+struct PushRuns {
+  int64_t offset[kMaxRuns];     // byte offset from both bases, multiple of 16
+  int64_t nbytes[kMaxRuns];     // multiple of 16
+  int32_t first_chunk[kMaxRuns + 1];
+  int32_t num_runs;
+};
+
+__global__ void __launch_bounds__(kPushThreads)
+kv_push_kernel(char* __restrict__ dst_base, const char* __restrict__ src_base, PushRuns runs) {
+  const int chunk = blockIdx.x;
+  int r = 0;
+  while (r + 1 < runs.num_runs && chunk >= runs.first_chunk[r + 1]) ++r;
+  const int64_t begin = (int64_t)(chunk - runs.first_chunk[r]) * kChunkBytes;
+  const int64_t end = min(begin + kChunkBytes, runs.nbytes[r]);
+  const uint4* src = reinterpret_cast<const uint4*>(src_base + runs.offset[r] + begin);
+  uint4* dst = reinterpret_cast<uint4*>(dst_base + runs.offset[r] + begin);
+  const int n = (int)((end - begin) >> 4);
+  // 4 independent 16-byte loads in flight per lane before the stores
+  int i = threadIdx.x;
+  for (; i + 3 * kPushThreads < n; i += 4 * kPushThreads) {
+    const uint4 a = src[i], b = src[i + kPushThreads], c = src[i + 2 * kPushThreads], d = src[i + 3 * kPushThreads];
+    dst[i] = a;
+    dst[i + kPushThreads] = b;
+    dst[i + 2 * kPushThreads] = c;
+    dst[i + 3 * kPushThreads] = d;
+  }
+  for (; i < n; i += kPushThreads) dst[i] = src[i];
+  // make this wave's stores visible beyond the device before the kernel retires
+  __threadfence_system();
+}
+
+__global__ void kv_signal_kernel(int32_t* flags, int slot, int32_t epoch) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    __threadfence_system();
+    __hip_atomic_store(flags + slot, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+// status[0] is set to 1 + slot when the bound runs out (the caller checks it on the host).
+__global__ void kv_wait_kernel(const int32_t* flags, int slot, int32_t epoch, long long max_spins,
+                               int32_t* status) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    long long spins = 0;
+    bool ok = false;
+    while (spins < max_spins) {
+      const int32_t v = __hip_atomic_load(flags + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (v - epoch >= 0) { ok = true; break; }
+      __builtin_amdgcn_s_sleep(32);
+      ++spins;
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);         // system scope
+    if (!ok) __hip_atomic_store(status, 1 + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+}  // namespace sw
+
+extern "C" {
+
+int sw_ipc_get_mem_handle(const void* dev_ptr, void* handle_out64) {
+  using namespace sw;
+  SW_CHECK_ARG(dev_ptr && handle_out64, "ipc_get_mem_handle: NULL argument");
+  static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t is expected to be 64 bytes");
+  hipIpcMemHandle_t h;
+  SW_CHECK_HIP(hipIpcGetMemHandle(&h, const_cast<void*>(dev_ptr)));
+  memcpy(handle_out64, &h, sizeof(h));
+  return SW_OK;
+}
+
+int sw_ipc_open_mem_handle(const void* handle64, void** dev_ptr_out) {
+  using namespace sw;
+  SW_CHECK_ARG(handle64 && dev_ptr_out, "ipc_open_mem_handle: NULL argument");
+  hipIpcMemHandle_t h;
+  memcpy(&h, handle64, sizeof(h));
+  SW_CHECK_HIP(hipIpcOpenMemHandle(dev_ptr_out, h, hipIpcMemLazyEnablePeerAccess));
+  return SW_OK;
+}
+
+int sw_ipc_close_mem_handle(void* dev_ptr) {
+  using namespace sw;
+  SW_CHECK_HIP(hipIpcCloseMemHandle(dev_ptr));
+  return SW_OK;
+}
+
+int sw_kv_push(void* dst_base, const void* src_base, const int64_t* offsets, const int64_t* nbytes,
+               int num_runs, void* stream) {
+  using namespace sw;
+  if (num_runs == 0) return SW_OK;
+  SW_CHECK_ARG(dst_base && src_base && offsets && nbytes && num_runs > 0, "kv_push: bad arguments");
+  SW_CHECK_ARG(reinterpret_cast<uintptr_t>(dst_base) % 16 == 0 && reinterpret_cast<uintptr_t>(src_base) % 16 == 0,
+               "kv_push: bases must be 16-byte aligned");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  int done = 0;
+  while (done < num_runs) {
+    PushRuns runs;
+    int chunks = 0, n = 0;
+    for (; n < kMaxRuns && done + n < num_runs; ++n) {
+      const int64_t off = offsets[done + n], nb = nbytes[done + n];
+      SW_CHECK_ARG(off >= 0 && nb > 0 && off % 16 == 0 && nb % 16 == 0,
+                   "kv_push: run %d (offset %lld, %lld bytes) is not 16-byte granular", done + n,
+                   (long long)off, (long long)nb);
+      runs.offset[n] = off;
+      runs.nbytes[n] = nb;
+      runs.first_chunk[n] = chunks;
+      const int64_t c = (nb + kChunkBytes - 1) / kChunkBytes;
+      SW_CHECK_ARG(chunks + c < (1 << 30), "kv_push: too many bytes in one call");
+      chunks += (int)c;
+    }
+    runs.first_chunk[n] = chunks;
+    runs.num_runs = n;
+    kv_push_kernel<<<chunks, kPushThreads, 0, s>>>(static_cast<char*>(dst_base),
+                                                   static_cast<const char*>(src_base), runs);
+    SW_CHECK_LAUNCH();
+    done += n;
+  }
+  return SW_OK;
+}
+
+int sw_kv_signal(int32_t* flags, int slot, int32_t epoch, void* stream) {
+  using namespace sw;
+  SW_CHECK_ARG(flags && slot >= 0, "kv_signal: bad arguments");
+  kv_signal_kernel<<<1, 64, 0, static_cast<hipStream_t>(stream)>>>(flags, slot, epoch);
+  SW_CHECK_LAUNCH();
+  return SW_OK;
+}
+
+int sw_kv_wait(const int32_t* flags, int slot, int32_t epoch, int64_t max_spins, int32_t* status,
+               void* stream) {
+  using namespace sw;
+  SW_CHECK_ARG(flags && status && slot >= 0 && max_spins > 0, "kv_wait: bad arguments");
+  kv_wait_kernel<<<1, 64, 0, static_cast<hipStream_t>(stream)>>>(flags, slot, epoch, (long long)max_spins, status);
+  SW_CHECK_LAUNCH();
+  return SW_OK;
+}
+
+}  // extern "C"

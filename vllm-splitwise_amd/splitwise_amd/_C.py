@@ -55,6 +55,12 @@ _SIGNATURES = {
     "sw_rotary_embedding": [_c_void_p, _c_void_p, _c_void_p, _c_i64, _c_int, _c_int, _c_int, _c_void_p, _c_int,
                             _c_int, _c_i64, _c_i64, _c_int, _c_void_p],
     "sw_silu_and_mul": [_c_void_p, _c_void_p, _c_i64, _c_int, _c_i64, _c_int, _c_void_p],
+    "sw_ipc_get_mem_handle": [_c_void_p, _c_void_p],
+    "sw_ipc_open_mem_handle": [_c_void_p, ctypes.POINTER(_c_void_p)],
+    "sw_ipc_close_mem_handle": [_c_void_p],
+    "sw_kv_push": [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p],
+    "sw_kv_signal": [_c_void_p, _c_int, ctypes.c_int32, _c_void_p],
+    "sw_kv_wait": [_c_void_p, _c_int, ctypes.c_int32, _c_i64, _c_void_p, _c_void_p],
 }
 
 _lib = None
@@ -371,6 +377,40 @@ def silu_and_mul(out: torch.Tensor, input: torch.Tensor) -> None:
                                               stride, _act_dtype(input), _stream(input)))
 
 
+# ------------------------------------------------------------------ KV transport
+def ipc_get_mem_handle(dev_ptr: int) -> bytes:
+    buf = ctypes.create_string_buffer(64)
+    _check(load_library().sw_ipc_get_mem_handle(dev_ptr, buf))
+    return buf.raw
+
+
+def ipc_open_mem_handle(handle: bytes) -> int:
+    out = _c_void_p()
+    _check(load_library().sw_ipc_open_mem_handle(ctypes.c_char_p(handle), ctypes.byref(out)))
+    return out.value
+
+
+def ipc_close_mem_handle(dev_ptr: int) -> None:
+    _check(load_library().sw_ipc_close_mem_handle(dev_ptr))
+
+
+def kv_push(dst_base: int, src_base: int, offsets: List[int], nbytes: List[int], stream: int) -> None:
+    n = len(offsets)
+    if n == 0:
+        return
+    off = (ctypes.c_int64 * n)(*offsets)
+    nb = (ctypes.c_int64 * n)(*nbytes)
+    _check(load_library().sw_kv_push(dst_base, src_base, ctypes.addressof(off), ctypes.addressof(nb), n, stream))
+
+
+def kv_signal(flags_ptr: int, slot: int, epoch: int, stream: int) -> None:
+    _check(load_library().sw_kv_signal(flags_ptr, slot, epoch, stream))
+
+
+def kv_wait(flags_ptr: int, slot: int, epoch: int, max_spins: int, status_ptr: int, stream: int) -> None:
+    _check(load_library().sw_kv_wait(flags_ptr, slot, epoch, max_spins, status_ptr, stream))
+
+
 # ------------------------------------------------------------------- cuda_utils
 def get_max_shared_memory_per_block_device_attribute(gpu: int) -> int:
     """``cuda_utils.get_max_shared_memory_per_block_device_attribute``
@@ -394,6 +434,14 @@ cache_ops = SimpleNamespace(
     copy_blocks=copy_blocks,
     swap_blocks=swap_blocks,
     convert_fp8_e5m2=convert_fp8_e5m2,
+)
+kv_ops = SimpleNamespace(
+    ipc_get_mem_handle=ipc_get_mem_handle,
+    ipc_open_mem_handle=ipc_open_mem_handle,
+    ipc_close_mem_handle=ipc_close_mem_handle,
+    kv_push=kv_push,
+    kv_signal=kv_signal,
+    kv_wait=kv_wait,
 )
 cuda_utils = SimpleNamespace(
     get_max_shared_memory_per_block_device_attribute=get_max_shared_memory_per_block_device_attribute,

@@ -278,7 +278,7 @@ class Scheduler:
             self.prefilling.add(group.request_id)
         outputs = SchedulerOutputs(scheduled, True, padded, {}, {}, {}, coalesce_blocks_by_id(blocks_to_nw),
                                    ignored)
-        return self._metadata(outputs, scheduled), outputs
+        return self._metadata(outputs, outputs.scheduled_seq_groups), outputs
 
     def prompt_step_done(self, request_ids: Iterable[str]) -> None:
         for rid in request_ids:
@@ -300,7 +300,7 @@ class Scheduler:
         tokens = sum(g.num_seqs(status=SequenceStatus.RUNNING) for g in ready)
         outputs = SchedulerOutputs(ready, False, tokens, blocks_to_swap_in, blocks_to_swap_out, blocks_to_copy,
                                    coalesce_blocks_by_id(blocks_to_nw), [])
-        return self._metadata(outputs, ready), outputs
+        return self._metadata(outputs, outputs.scheduled_seq_groups), outputs
 
     # -------------------------------------------------------------- bookkeeping
     def fork_seq(self, parent_seq: Sequence, child_seq: Sequence) -> None:

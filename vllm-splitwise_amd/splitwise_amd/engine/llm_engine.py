@@ -44,6 +44,9 @@ class LLMEngine:
         self.scheduler = Scheduler(scheduler_config, cache_config, None,
                                    track_prompt_blocks=parallel_config.sep_prompt_token)
         self.stat_logger = StatLogger(local_interval=5.0) if log_stats else None
+        # split pools: run a prompt step and a decode step concurrently when the executor can
+        self.overlap_pools = parallel_config.sep_prompt_token and hasattr(self.model_executor, "execute_split")
+        self._slot_epoch: Dict[int, int] = {}
 
     @classmethod
     def from_engine_args(cls, engine_args: EngineArgs, **kwargs) -> "LLMEngine":
@@ -111,9 +114,38 @@ class LLMEngine:
             self.stat_logger.log(self._get_stats(scheduler_outputs, scheduled, now))
         return request_outputs
 
+    def _step_split(self) -> List[RequestOutput]:
+        """One decode step on the token pool and one prompt step on the prompt pool, in flight
+        together.  Hand-off epochs are counted here, once per prompt step of a slot, and given to
+        both pools, so a signal and the wait that belongs to it always agree."""
+        metas_d, outs_d = self.scheduler.schedule_decodes()
+        metas_p, outs_p = self.scheduler.schedule_prompts()
+        prompt_kwargs = decode_kwargs = None
+        if metas_p:
+            for slot in outs_p.blocks_to_nw:
+                self._slot_epoch[slot] = self._slot_epoch.get(slot, 0) + 1
+            prompt_kwargs = dict(seq_group_metadata_list=metas_p, blocks_to_swap_in={}, blocks_to_swap_out={},
+                                 blocks_to_copy={}, blocks_to_nw=outs_p.blocks_to_nw,
+                                 nw_epochs={s: self._slot_epoch[s] for s in outs_p.blocks_to_nw})
+        if not outs_d.is_empty():
+            decode_kwargs = dict(seq_group_metadata_list=metas_d, blocks_to_swap_in=outs_d.blocks_to_swap_in,
+                                 blocks_to_swap_out=outs_d.blocks_to_swap_out, blocks_to_copy=outs_d.blocks_to_copy,
+                                 blocks_to_nw=outs_d.blocks_to_nw,
+                                 nw_epochs={s: self._slot_epoch.get(s, 0) for s in outs_d.blocks_to_nw})
+        prompt_out, decode_out = self.model_executor.execute_split(prompt_kwargs, decode_kwargs)
+        outputs: List[RequestOutput] = []
+        if decode_out is not None and metas_d:
+            outputs += self._process_model_outputs(decode_out, outs_d)
+        if prompt_out is not None or outs_p.ignored_seq_groups:
+            outputs += self._process_model_outputs(prompt_out or SamplerOutput([]), outs_p)
+            self.scheduler.prompt_step_done([m.request_id for m in metas_p])
+        return outputs
+
     def step(self) -> List[RequestOutput]:
         """One scheduling decision, one model step on the executor, outputs appended
         (vllm/engine/llm_engine.py:571-633)."""
+        if self.overlap_pools:
+            return self._step_split()
         metas, scheduler_outputs = self.scheduler.schedule()
         if not scheduler_outputs.is_empty():
             output = self.model_executor.execute_model(

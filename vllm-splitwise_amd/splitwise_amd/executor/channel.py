@@ -1,0 +1,41 @@
+"""Control-plane channels between the engine process and a remote worker process: small pickled
+messages only (step commands, sampled tokens, IPC handles).  The reference uses Ray RPC for this
+(vllm/executor/ray_gpu_executor.py:343-452); the KV bytes never travel here."""
+from typing import Any
+
+
+class PipeChannel:
+    """A multiprocessing connection (full duplex)."""
+
+    def __init__(self, conn) -> None:
+        self.conn = conn
+
+    def send(self, obj: Any) -> None:
+        self.conn.send(obj)
+
+    def recv(self) -> Any:
+        return self.conn.recv()
+
+    def close(self) -> None:
+        self.conn.close()
+
+
+class DistChannel:
+    """torch.distributed point-to-point objects over a gloo group (ranks launched by torchrun)."""
+
+    def __init__(self, peer_rank: int, group=None) -> None:
+        self.peer = peer_rank
+        self.group = group
+
+    def send(self, obj: Any) -> None:
+        import torch.distributed as dist
+        dist.send_object_list([obj], dst=self.peer, group=self.group)
+
+    def recv(self) -> Any:
+        import torch.distributed as dist
+        box = [None]
+        dist.recv_object_list(box, src=self.peer, group=self.group)
+        return box[0]
+
+    def close(self) -> None:
+        pass

@@ -1,0 +1,61 @@
+"""The command loop of a worker that lives in another process (the token worker of a split pair)."""
+import traceback
+from typing import Any, Dict
+
+import torch
+
+from ..config import DeviceConfig
+from ..worker.worker import Worker
+
+
+def make_exchange(channel):
+    """Symmetric swap with the paired worker over the control channel."""
+    def exchange(obj):
+        channel.send(("kv_exchange", obj))
+        tag, peer = channel.recv()
+        assert tag == "kv_exchange", tag
+        return peer
+    return exchange
+
+
+def worker_loop(channel, cfg: Dict[str, Any]) -> None:
+    """cfg: model_config, parallel_config, scheduler_config, cache_config, rank, local_rank, transport."""
+    worker = None
+    try:
+        worker = Worker(cfg["model_config"], cfg["parallel_config"], cfg["scheduler_config"], DeviceConfig("cuda"),
+                        local_rank=cfg["local_rank"], rank=cfg["rank"], kv_cache_dtype=cfg["cache_config"].cache_dtype,
+                        is_driver_worker=True,
+                        kv_transport_init={"exchange": make_exchange(channel), "transport": cfg["transport"]})
+        while True:
+            msg = channel.recv()
+            cmd, args = msg[0], msg[1:]
+            if cmd == "shutdown":
+                channel.send(("ok", None))
+                break
+            try:
+                if cmd == "call":
+                    name, kwargs = args
+                    result = getattr(worker, name)(**kwargs)
+                elif cmd == "execute":
+                    (kwargs,) = args
+                    result = worker.execute_model(**kwargs)
+                elif cmd == "bytes_pushed":
+                    comm = worker.kvcache_comm_manager.kvcache_comm
+                    result = comm.bytes_pushed if comm else 0
+                else:
+                    raise ValueError(f"unknown command {cmd!r}")
+                channel.send(("ok", result))
+            except Exception as exc:            # report and keep serving: the engine decides
+                channel.send(("error", f"{type(exc).__name__}: {exc}\n{traceback.format_exc()}"))
+    finally:
+        if worker is not None and worker.kvcache_comm_manager is not None:
+            try:
+                worker.destroy_kvcache_comm()
+            except Exception:
+                pass
+
+
+def spawn_entry(conn, cfg: Dict[str, Any]) -> None:
+    from .channel import PipeChannel
+    torch.cuda.set_device(cfg["local_rank"])
+    worker_loop(PipeChannel(conn), cfg)

@@ -111,9 +111,14 @@ class Attention(nn.Module):
 
         if input_metadata.is_prompt:
             if input_metadata.blocks_to_nw and self.kvcache_comm_manager is not None:
-                for sem_id, runs in input_metadata.blocks_to_nw.items():
-                    for block_start, num_blocks in runs:
-                        self.kvcache_comm_manager.put(sem_id, self.layer_id, block_start, num_blocks)
+                comm = self.kvcache_comm_manager
+                if hasattr(comm, "put_many"):
+                    # every run of every hand-off slot, K and V, in one launch per layer
+                    comm.put_many(self.layer_id, [r for runs in input_metadata.blocks_to_nw.values() for r in runs])
+                else:
+                    for sem_id, runs in input_metadata.blocks_to_nw.items():
+                        for block_start, num_blocks in runs:
+                            comm.put(sem_id, self.layer_id, block_start, num_blocks)
             output = torch.empty_like(query)
             _C.ops.prefill_attention(output, query, key, value, input_metadata.start_loc,
                                      input_metadata.prompt_lens, input_metadata.max_seq_len, self.scale,

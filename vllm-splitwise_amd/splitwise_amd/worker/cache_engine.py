@@ -6,7 +6,7 @@ value cache [num_blocks, kv_heads, head_size, block_size]; pinned host mirrors f
 swap / copy run on a side stream with one event per layer.  This layout is also the wire
 format of the KV push between the prompt and token pools, so it is kept bit for bit.
 """
-from typing import Dict, List, Tuple
+from typing import Dict, List, Optional, Tuple
 
 import torch
 
@@ -37,7 +37,8 @@ class CacheEngine:
         self.num_cpu_blocks = cache_config.num_cpu_blocks
         self.dtype = _cache_torch_dtype(cache_config.cache_dtype, model_config.dtype)
         self.device = device
-        self.gpu_cache = self._allocate(self.num_gpu_blocks, device, pinned=False)
+        self.gpu_slab: Optional[torch.Tensor] = None
+        self.gpu_cache = self._allocate_gpu_slab(self.num_gpu_blocks, device)
         self.cpu_cache = self._allocate(self.num_cpu_blocks, torch.device("cpu"), pinned=device.type == "cuda")
         self.cache_stream = torch.cuda.Stream(device) if device.type == "cuda" else None
         self.events = ([torch.cuda.Event() for _ in range(self.num_layers)] if device.type == "cuda" else [])
@@ -48,6 +49,26 @@ class CacheEngine:
 
     def get_value_block_shape(self) -> Tuple[int, int, int]:
         return (self.num_heads, self.head_size, self.block_size)
+
+    def _allocate_gpu_slab(self, num_blocks: int, device: torch.device) -> List[KVCache]:
+        """Every layer's K and V tensor is a view of ONE device allocation (plus a small flag area
+        at its end): a single IPC handle then exports the whole cache to the paired worker, and a
+        byte offset means the same block on both sides of a prompt/token pair."""
+        from .kv_comm import slab_layout
+        es = torch.tensor([], dtype=self.dtype).element_size()
+        kshape, vshape = self.get_key_block_shape(), self.get_value_block_shape()
+        block_elems = self.num_heads * self.head_size * self.block_size
+        offsets, _, total = slab_layout(self.num_layers, block_elems * es, num_blocks)
+        slab = torch.empty(total, dtype=torch.uint8, device=device)
+        self.gpu_slab = slab
+        n = num_blocks * block_elems * es
+        cache: List[KVCache] = []
+        for k_off, v_off in offsets:
+            k = slab[k_off:k_off + n].view(self.dtype).view(num_blocks, *kshape)
+            v = slab[v_off:v_off + n].view(self.dtype).view(num_blocks, *vshape)
+            k._slab = slab
+            cache.append((k, v))
+        return cache
 
     def _allocate(self, num_blocks: int, device: torch.device, pinned: bool) -> List[KVCache]:
         cache: List[KVCache] = []

@@ -1,0 +1,202 @@
+"""KV-cache transport between a prompt worker and its paired token worker.
+
+Interface of vllm/worker/comm_utils.py:150-222 (``KVCacheCommManager``): ``setup_comm``,
+``put(sem_id, layer_id, block_start, num_blocks)``, ``signal_and_flush(sem_id)``,
+``wait(sem_id)``, ``destroy_comm``; peer of rank r is ``(r + num_prompt_workers) % world``
+(:165); a put moves ``num_blocks`` blocks of the layer's K tensor and of its V tensor to the
+SAME byte offset in the peer's tensors (:132-147).  All three data operations are
+stream-ordered and never block the host.
+
+Instead of MSCCL++ proxy channels (a CPU thread issuing the copies), the token worker's cache
+slab is mapped into the prompt worker's address space with HIP IPC and the GPU stores into it
+directly over xGMI (``transport="kernel"``: sw_kv_push / sw_kv_signal / sw_kv_wait).  A second
+transport, ``"runtime"``, lets the HIP runtime move the same bytes and the flag word with
+stream-ordered device-to-device copies into the mapped peer slab (the wait is the same
+kernel); it exists as a fallback should direct peer stores from a kernel misbehave on a
+system.  (Inter-process HIP events are not usable for the hand-off: hipIpcGetEventHandle
+fails on this stack.)
+"""
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from .. import _C
+from ..utils import MAX_SLOT_IDS
+
+HEAD_TYPES = [0, 1]               # 0 = keys, 1 = values (comm_utils.py:17)
+FLAG_BYTES = 4096                 # MAX_SLOT_IDS int32 flags + a status word, padded
+_MAX_SPINS = 5_000_000            # bounded wait, about 10 s
+
+
+class _DevicePtrView:
+    """Exposes raw device memory to torch through __cuda_array_interface__."""
+
+    def __init__(self, ptr: int, nbytes: int) -> None:
+        self.__cuda_array_interface__ = {"data": (ptr, False), "shape": (nbytes,), "typestr": "|u1",
+                                         "strides": None, "version": 2}
+
+
+def slab_layout(num_layers: int, key_block_bytes: int, num_blocks: int) -> Tuple[List[Tuple[int, int]], int, int]:
+    """Byte offsets of every layer's (K, V) tensor inside one cache slab, the offset of the
+    flag area and the slab size.  Both workers of a pair compute the same layout."""
+    offsets = []
+    cursor = 0
+    per_tensor = key_block_bytes * num_blocks
+    per_tensor_aligned = -(-per_tensor // 256) * 256
+    for _ in range(num_layers):
+        k_off = cursor
+        v_off = cursor + per_tensor_aligned
+        offsets.append((k_off, v_off))
+        cursor += 2 * per_tensor_aligned
+    return offsets, cursor, cursor + FLAG_BYTES
+
+
+class KVCacheCommunicator:
+    """The data path once both sides are connected (comm_utils.py:90-147)."""
+
+    def __init__(self, block_size: int, layer_offsets: List[Tuple[int, int]], local_base: int, peer_base: int,
+                 flags_offset: int, transport: str, device: torch.device) -> None:
+        self.block_size = block_size                  # bytes of one block of one tensor
+        self.layer_offsets = layer_offsets
+        self.local_base = local_base
+        self.peer_base = peer_base
+        self.flags_offset = flags_offset
+        self.transport = transport
+        self.device = device
+        self.signal_epoch = [0] * MAX_SLOT_IDS
+        self.wait_epoch = [0] * MAX_SLOT_IDS
+        self.bytes_pushed = 0
+        # runtime transport state
+        self.local_bytes: Optional[torch.Tensor] = None
+        self.peer_bytes: Optional[torch.Tensor] = None
+
+    def _stream(self) -> int:
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def put_many(self, layer_id: int, runs: Sequence[Tuple[int, int]]) -> None:
+        """All (block_start, num_blocks) runs of one layer, K and V, in one launch."""
+        if not runs:
+            return
+        k_off, v_off = self.layer_offsets[layer_id]
+        offsets, sizes = [], []
+        for block_start, num_blocks in runs:
+            for base in (k_off, v_off):
+                offsets.append(base + block_start * self.block_size)
+                sizes.append(num_blocks * self.block_size)
+        self.bytes_pushed += sum(sizes)
+        if self.transport == "kernel":
+            _C.kv_ops.kv_push(self.peer_base, self.local_base, offsets, sizes, self._stream())
+        else:
+            for off, n in zip(offsets, sizes):
+                self.peer_bytes[off:off + n].copy_(self.local_bytes[off:off + n], non_blocking=True)
+
+    def put(self, sem_id: int, layer_id: int, block_start: int, num_blocks: int) -> None:
+        del sem_id                                    # ordering is by stream, not by channel
+        self.put_many(layer_id, [(block_start, num_blocks)])
+
+    def signal_and_flush(self, sem_id: int, epoch: Optional[int] = None) -> None:
+        if epoch is None:
+            epoch = self.signal_epoch[sem_id] + 1
+        self.signal_epoch[sem_id] = epoch
+        if self.transport == "kernel":
+            _C.kv_ops.kv_signal(self.peer_base + self.flags_offset, sem_id, epoch, self._stream())
+        else:
+            word = torch.tensor([epoch], dtype=torch.int32, device=self.device).view(torch.uint8)
+            off = self.flags_offset + 4 * sem_id
+            self.peer_bytes[off:off + 4].copy_(word, non_blocking=True)      # after the data copies, in stream order
+
+    def wait(self, sem_id: int, epoch: Optional[int] = None) -> None:
+        if epoch is None:
+            epoch = self.wait_epoch[sem_id] + 1
+        self.wait_epoch[sem_id] = epoch
+        flags = self.local_base + self.flags_offset
+        status = flags + 4 * MAX_SLOT_IDS
+        _C.kv_ops.kv_wait(flags, sem_id, epoch, _MAX_SPINS, status, self._stream())
+
+
+class KVCacheCommManager:
+    """``init`` carries what the reference's ``mscclpp_init_method`` stands for: how to reach the
+    peer.  Keys: ``exchange`` -- callable(obj) -> the paired worker's obj (a symmetric swap over
+    any control channel); ``transport`` -- "kernel" (default) or "runtime"."""
+
+    def __init__(self, rank: int, world_size: int, num_prompt_workers: int, init: Dict) -> None:
+        self.rank = rank
+        self.world_size = world_size
+        self.num_prompt_workers = num_prompt_workers
+        self.corr_worker_rank = (rank + num_prompt_workers) % world_size
+        self.is_prompt_side = rank < num_prompt_workers
+        self.exchange: Callable = init["exchange"]
+        self.transport: str = init.get("transport", "kernel")
+        if self.transport not in ("kernel", "runtime"):
+            raise ValueError(f"unknown KV transport {self.transport!r}")
+        self.kvcache_comm: Optional[KVCacheCommunicator] = None
+        self._peer_mapping: Optional[int] = None
+        self._slab: Optional[torch.Tensor] = None
+
+    def setup_comm(self, num_layers: int, kv_cache: List[Tuple[torch.Tensor, torch.Tensor]]) -> None:
+        """Registers every layer's K and V tensor (they must be views of one slab, see
+        ``CacheEngine``) and connects to the peer."""
+        k0 = kv_cache[0][0]
+        slab = getattr(k0, "_slab", None)
+        if slab is None:
+            raise RuntimeError("KV transport needs the cache allocated as one slab (CacheEngine(slab=True))")
+        self._slab = slab
+        device = slab.device
+        block_bytes = k0[0].numel() * k0.element_size()
+        base = slab.data_ptr()
+        layer_offsets = []
+        for layer_id in range(num_layers):
+            k, v = kv_cache[layer_id]
+            layer_offsets.append((k.data_ptr() - base, v.data_ptr() - base))
+        flags_offset = slab.numel() - FLAG_BYTES
+        slab[flags_offset:].zero_()
+        torch.cuda.synchronize(device)
+        info = {"rank": self.rank, "nbytes": slab.numel(), "layer_offsets": layer_offsets,
+                "handle": _C.kv_ops.ipc_get_mem_handle(base), "pid_device": (torch.cuda.current_device(),)}
+        peer = self.exchange(info)
+        if peer["rank"] != self.corr_worker_rank:
+            raise RuntimeError(f"KV transport paired rank {self.rank} with {peer['rank']}, expected "
+                               f"{self.corr_worker_rank}")
+        if peer["nbytes"] != info["nbytes"] or peer["layer_offsets"] != layer_offsets:
+            raise RuntimeError("prompt and token workers disagree on the cache layout")
+        peer_base = 0
+        if self.is_prompt_side:
+            peer_base = _C.kv_ops.ipc_open_mem_handle(peer["handle"])
+            self._peer_mapping = peer_base
+        comm = KVCacheCommunicator(block_bytes, layer_offsets, base, peer_base, flags_offset, self.transport, device)
+        if self.transport == "runtime":
+            comm.local_bytes = slab
+            if self.is_prompt_side:
+                comm.peer_bytes = torch.as_tensor(_DevicePtrView(peer_base, slab.numel()), device=device)
+        self.kvcache_comm = comm
+        self.exchange({"rank": self.rank, "ready": True})        # both sides mapped before any put
+
+    def destroy_comm(self) -> None:
+        if self.kvcache_comm is not None:
+            torch.cuda.synchronize(self.kvcache_comm.device)
+        if self._peer_mapping is not None:
+            _C.kv_ops.ipc_close_mem_handle(self._peer_mapping)
+            self._peer_mapping = None
+        self.kvcache_comm = None
+
+    def check_status(self) -> None:
+        """Raises if a wait ran out of its spin bound (host-synchronising: call off the hot path)."""
+        comm = self.kvcache_comm
+        if comm is None or self._slab is None:
+            return
+        off = comm.flags_offset + 4 * MAX_SLOT_IDS
+        status = int(self._slab[off:off + 4].view(torch.int32).item())
+        if status != 0:
+            raise RuntimeError(f"KV hand-off wait timed out on slot {status - 1}")
+
+    def wait(self, sem_id: int, epoch: Optional[int] = None) -> None:
+        self.kvcache_comm.wait(sem_id, epoch)
+
+    def signal_and_flush(self, sem_id: int, epoch: Optional[int] = None) -> None:
+        self.kvcache_comm.signal_and_flush(sem_id, epoch)
+
+    def put(self, sem_id: int, layer_id: int, block_start: int, num_blocks: int) -> None:
+        self.kvcache_comm.put(sem_id, layer_id, block_start, num_blocks)
+
+    def put_many(self, layer_id: int, runs: Sequence[Tuple[int, int]]) -> None:
+        self.kvcache_comm.put_many(layer_id, runs)

@@ -71,7 +71,9 @@ class Worker:
         self.model_runner.device = self.device
         torch.cuda.empty_cache()
         self.init_gpu_memory = torch.cuda.mem_get_info()[0]
-        if self.parallel_config.world_size > 1 and not dist.is_initialized():
+        # only tensor parallelism needs a process group: a prompt/token pair talks through the KV
+        # transport and the engine's control channel
+        if self.parallel_config.tensor_parallel_size > 1 and not dist.is_initialized():
             if not self.distributed_init_method:
                 raise ValueError("distributed_init_method must be set if torch.distributed is not already "
                                  "initialized")
@@ -175,8 +177,12 @@ class Worker:
                       blocks_to_swap_in: Optional[Dict[int, int]] = None,
                       blocks_to_swap_out: Optional[Dict[int, int]] = None,
                       blocks_to_copy: Optional[Dict[int, List[int]]] = None,
-                      blocks_to_nw: Optional[Dict[int, List[Tuple[int, int]]]] = None) -> Optional[SamplerOutput]:
+                      blocks_to_nw: Optional[Dict[int, List[Tuple[int, int]]]] = None,
+                      nw_epochs: Optional[Dict[int, int]] = None) -> Optional[SamplerOutput]:
+        """``nw_epochs`` (optional) gives the hand-off count of every slot in ``blocks_to_nw`` as the
+        engine counts it; without it each side counts its own signals / waits."""
         blocks_to_nw = blocks_to_nw or {}
+        nw_epochs = nw_epochs or {}
         self.cache_swap(blocks_to_swap_in or {}, blocks_to_swap_out or {}, blocks_to_copy or {})
         if not seq_group_metadata_list:
             return SamplerOutput([])
@@ -184,11 +190,11 @@ class Worker:
         comm = self.kvcache_comm_manager
         if blocks_to_nw and comm is not None and self.is_token_worker() and not is_prompt:
             for sem_id in blocks_to_nw:
-                comm.wait(sem_id)
+                comm.wait(sem_id, nw_epochs.get(sem_id))
         output = self.model_runner.execute_model(seq_group_metadata_list, self.gpu_cache, blocks_to_nw)
         if blocks_to_nw and comm is not None and self.is_prompt_worker() and is_prompt:
             for sem_id in blocks_to_nw:
-                comm.signal_and_flush(sem_id)
+                comm.signal_and_flush(sem_id, nw_epochs.get(sem_id))
         return output
 
     # ------------------------------------------- transport self-test (worker.py:350-386)
