@@ -30,6 +30,11 @@ struct PushRuns {
   int32_t num_runs;
 };
 
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
+
+// Stores go out write-through at system scope (sc0 sc1): the bytes leave this GPU's caches as
+// they are issued, so no cache write-back is needed before the hand-off flag is raised; each
+// wave only drains its own store queue before it retires.
 __global__ void __launch_bounds__(kPushThreads)
 kv_push_kernel(char* __restrict__ dst_base, const char* __restrict__ src_base, PushRuns runs) {
   const int chunk = blockIdx.x;
@@ -37,21 +42,29 @@ kv_push_kernel(char* __restrict__ dst_base, const char* __restrict__ src_base, P
   while (r + 1 < runs.num_runs && chunk >= runs.first_chunk[r + 1]) ++r;
   const int64_t begin = (int64_t)(chunk - runs.first_chunk[r]) * kChunkBytes;
   const int64_t end = min(begin + kChunkBytes, runs.nbytes[r]);
+  const int nbytes = (int)(end - begin);
   const uint4* src = reinterpret_cast<const uint4*>(src_base + runs.offset[r] + begin);
-  uint4* dst = reinterpret_cast<uint4*>(dst_base + runs.offset[r] + begin);
-  const int n = (int)((end - begin) >> 4);
-  // 4 independent 16-byte loads in flight per lane before the stores
+  // wave-uniform destination descriptor for this chunk (bounds-checked by the hardware)
+  uint64_t d = reinterpret_cast<uint64_t>(dst_base + runs.offset[r] + begin);
+  const uint32_t d_lo = __builtin_amdgcn_readfirstlane((uint32_t)d);
+  const uint32_t d_hi = __builtin_amdgcn_readfirstlane((uint32_t)(d >> 32));
+  char* d_uniform = reinterpret_cast<char*>(((uint64_t)d_hi << 32) | d_lo);
+  const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(d_uniform, 0, nbytes, 0x00020000);
+  constexpr int kAuxSystem = 17;                      // sc0 | sc1
+  const int n = nbytes >> 4;
   int i = threadIdx.x;
   for (; i + 3 * kPushThreads < n; i += 4 * kPushThreads) {
-    const uint4 a = src[i], b = src[i + kPushThreads], c = src[i + 2 * kPushThreads], d = src[i + 3 * kPushThreads];
-    dst[i] = a;
-    dst[i + kPushThreads] = b;
-    dst[i + 2 * kPushThreads] = c;
-    dst[i + 3 * kPushThreads] = d;
+    const uint4 a = src[i], b = src[i + kPushThreads], c = src[i + 2 * kPushThreads], e = src[i + 3 * kPushThreads];
+    __builtin_amdgcn_raw_buffer_store_b128(u32x4{a.x, a.y, a.z, a.w}, rsrc, i * 16, 0, kAuxSystem);
+    __builtin_amdgcn_raw_buffer_store_b128(u32x4{b.x, b.y, b.z, b.w}, rsrc, (i + kPushThreads) * 16, 0, kAuxSystem);
+    __builtin_amdgcn_raw_buffer_store_b128(u32x4{c.x, c.y, c.z, c.w}, rsrc, (i + 2 * kPushThreads) * 16, 0, kAuxSystem);
+    __builtin_amdgcn_raw_buffer_store_b128(u32x4{e.x, e.y, e.z, e.w}, rsrc, (i + 3 * kPushThreads) * 16, 0, kAuxSystem);
   }
-  for (; i < n; i += kPushThreads) dst[i] = src[i];
-  // make this wave's stores visible beyond the device before the kernel retires
-  __threadfence_system();
+  for (; i < n; i += kPushThreads) {
+    const uint4 a = src[i];
+    __builtin_amdgcn_raw_buffer_store_b128(u32x4{a.x, a.y, a.z, a.w}, rsrc, i * 16, 0, kAuxSystem);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 __global__ void kv_signal_kernel(int32_t* flags, int slot, int32_t epoch) {

@@ -36,6 +36,19 @@ class _DevicePtrView:
                                          "strides": None, "version": 2}
 
 
+_FOUR_GIB = 1 << 32
+_IPC_MARGIN = 64 << 20            # covers the caching allocator's rounding of large requests
+
+
+def _ipc_safe_size(nbytes: int) -> int:
+    """hipIpcOpenMemHandle on ROCm 7.2 never returns for an allocation whose size modulo 4 GiB
+    is 2 GiB or more (measured: 1.99, 5.9, 17, 41.9 GiB open in a millisecond; 2.01, 3.9, 6, 19,
+    23, 42.1 GiB hang).  Sizes in that band are padded up to the next multiple of 4 GiB."""
+    if nbytes % _FOUR_GIB > (_FOUR_GIB // 2) - _IPC_MARGIN:
+        nbytes = -(-nbytes // _FOUR_GIB) * _FOUR_GIB
+    return nbytes
+
+
 def slab_layout(num_layers: int, key_block_bytes: int, num_blocks: int) -> Tuple[List[Tuple[int, int]], int, int]:
     """Byte offsets of every layer's (K, V) tensor inside one cache slab, the offset of the
     flag area and the slab size.  Both workers of a pair compute the same layout."""
@@ -48,7 +61,8 @@ def slab_layout(num_layers: int, key_block_bytes: int, num_blocks: int) -> Tuple
         v_off = cursor + per_tensor_aligned
         offsets.append((k_off, v_off))
         cursor += 2 * per_tensor_aligned
-    return offsets, cursor, cursor + FLAG_BYTES
+    total = _ipc_safe_size(cursor + FLAG_BYTES)
+    return offsets, total - FLAG_BYTES, total
 
 
 class KVCacheCommunicator:
@@ -141,6 +155,9 @@ class KVCacheCommManager:
         if slab is None:
             raise RuntimeError("KV transport needs the cache allocated as one slab (CacheEngine(slab=True))")
         self._slab = slab
+        if _ipc_safe_size(slab.numel()) != slab.numel():
+            raise RuntimeError(f"cache slab of {slab.numel()} bytes cannot be mapped by a peer process on this "
+                               "runtime; allocate it through slab_layout()")
         device = slab.device
         block_bytes = k0[0].numel() * k0.element_size()
         base = slab.data_ptr()
