@@ -174,6 +174,56 @@ int sw_kv_signal(int32_t* flags, int slot, int32_t epoch, void* stream);
 int sw_kv_wait(const int32_t* flags, int slot, int32_t epoch, int64_t max_spins,
                int32_t* status, void* stream);
 
+/* ------------------------------------------------ int4 weight-only linear layers
+ * fp16 activations and scales only (vllm/model_executor/layers/quantization/gptq.py:50-51,
+ * awq.py:45-46); 4-bit weights only (the reference's 2/3/8-bit GPTQ kernels are not provided:
+ * SW_ERR_INVALID).  W[k][n] = fp16((q - zero) * scale); C = A.W accumulated in fp32.
+ *
+ * Workspace: the fused GEMMs split k across workgroups and combine fp32 partial tiles in
+ * device memory.  `workspace` must hold at least 16 KiB, whose first 16 KiB are ZERO the first
+ * time it is passed and are left zero by every call; a larger workspace allows more splits
+ * (sw_quant_gemm_workspace_bytes gives a size that never limits them).  Calls that share a
+ * workspace must be ordered on one stream.                                              */
+int64_t sw_quant_gemm_workspace_bytes(int M, int N, int K);
+
+/* csrc/quantization/gptq/q_gemm.cu:2748-2769 gptq_shuffle: in place, once after loading.
+ *   qweight  int32 [K/8, N], nibble i of a word = row 8r+i
+ *   q_perm   int32 [K] or NULL: row order that makes groups sequential (argsort of g_idx);
+ *            needs `scratch` of K/8*N*4 bytes (the reference allocates and frees its own)
+ * Asynchronous on `stream` (the reference synchronises the device).                     */
+int sw_gptq_shuffle(uint32_t* qweight, const int32_t* q_perm, int K, int N, int bit,
+                    void* scratch, void* stream);
+
+/* csrc/quantization/gptq/q_gemm.cu:2712-2746 gptq_gemm: c[M,N] = a[M,K] . W.
+ *   qzeros int32 [groups, N/8] (nibble n%8, stored value is zero-1), scales fp16 [groups, N]
+ *   use_exllama != 0: qweight was shuffled; g_idx = the q_perm given to sw_gptq_shuffle or NULL
+ *   use_exllama == 0: plain qweight; g_idx int32 [K] = group of every row (required)
+ * One code path for every M (the reference switches to reconstruct + BLAS above 50 rows).  */
+int sw_gptq_gemm(void* c, const void* a, const uint32_t* qweight, const uint32_t* qzeros,
+                 const void* scales, const int32_t* g_idx, int M, int N, int K, int groups,
+                 int use_exllama, int bit, void* workspace, int64_t workspace_bytes,
+                 void* stream);
+
+/* csrc/quantization/gptq/q_gemm.cu:2820-2861 dequant_gptq (kernels :920-1037, :1517-1561):
+ * out fp16 [K, N] in ORIGINAL row order, bit-identical to the reference's reconstruction.  */
+int sw_gptq_dequant(void* out, const uint32_t* qweight, const uint32_t* qzeros,
+                    const void* scales, const int32_t* g_idx, int K, int N, int groups,
+                    int use_exllama, int bit, void* stream);
+
+/* csrc/quantization/awq/gemm_kernels.cu:648-705 awq_gemm: c[M,N] = a[M,K] . W.
+ *   qweight int32 [K, N/8], qzeros int32 [K/group_size, N/8], scales fp16 [K/group_size, N];
+ *   nibble j of a word is logical column {0,2,4,6,1,3,5,7}[j] of its 8 columns
+ *   (dequantize.cuh:40-56).  The reference's split_k_iters has no counterpart: the split
+ *   is chosen here and the partials are combined in the same launch.
+ * Errors mirror the reference's argument checks (:671-678).                               */
+int sw_awq_gemm(void* c, const void* a, const uint32_t* qweight, const void* scales,
+                const uint32_t* qzeros, int M, int K, int N, int group_size,
+                void* workspace, int64_t workspace_bytes, void* stream);
+
+/* csrc/quantization/awq/gemm_kernels.cu:585-640 awq_dequantize: out fp16 [K, N].          */
+int sw_awq_dequantize(void* out, const uint32_t* qweight, const void* scales,
+                      const uint32_t* qzeros, int K, int N, int group_size, void* stream);
+
 /* -------------------------------------------- row-wise operators beside the path
  * csrc/layernorm_kernels.cu:70-118 rms_norm / fused_add_rms_norm.
  *   out = (act)(x * rsqrt(mean(x^2) + eps)) * weight, per row of hidden_size elements.

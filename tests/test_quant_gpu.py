@@ -1,0 +1,182 @@
+"""int4 dequant-GEMM through the C ABI against the CPU restatement (oracle/quant.py).
+
+Integer and format work (shuffle, reconstruction) is compared bit for bit.  The GEMMs
+accumulate in fp32 and round once to fp16; the oracle multiplies the same fp16 weights in fp32,
+so the tolerance below is one fp16 rounding of the result (rtol 1.5e-3) plus an absolute term
+for cancellation (1e-4 of the largest result).  The reference's own fused kernels are looser
+than this: they add fp16 partial sums with atomics (q_gemm.cu:329-336).  No reference fixture
+exists for 4-bit GPTQ or AWQ: parity unpinned.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import quant
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1.5e-3
+ATOL_FRAC = 1e-4
+
+
+def _dev(x, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(x))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda()
+
+
+def _close(got: torch.Tensor, ref: np.ndarray):
+    got = got.float().cpu().numpy()
+    np.testing.assert_allclose(got, ref, rtol=RTOL, atol=ATOL_FRAC * float(np.abs(ref).max()) + 1e-7)
+
+
+def _gptq_case(k, n, group, seed, act_order=False):
+    rng = np.random.default_rng(seed)
+    q = rng.integers(0, 16, size=(k, n))
+    groups = k // group
+    zeros = rng.integers(1, 17, size=(groups, n))
+    scales = (rng.uniform(0.5, 1.5, size=(groups, n)) * 1e-2).astype(np.float16)
+    g_idx = np.arange(k) // group
+    if act_order:
+        g_idx = rng.permutation(g_idx)
+    qweight, qzeros = quant.gptq_pack(q, zeros)
+    return qweight, qzeros, scales, g_idx.astype(np.int32)
+
+
+@pytest.mark.parametrize("k,n", [(64, 8), (256, 136), (1024, 512)])
+def test_gptq_shuffle_bit_exact(k, n):
+    from splitwise_amd import _C
+    qweight, _, _, _ = _gptq_case(k, n, 32, k + n)
+    dev = _dev(qweight)
+    _C.ops.gptq_shuffle(dev, torch.empty((1, 1), device="meta"), 4)
+    assert np.array_equal(dev.cpu().numpy(), quant.gptq_shuffle(qweight))
+
+
+def test_gptq_shuffle_with_row_permutation_bit_exact():
+    from splitwise_amd import _C
+    qweight, _, _, g_idx = _gptq_case(512, 264, 64, 5, act_order=True)
+    perm = np.argsort(g_idx, kind="stable").astype(np.int32)
+    dev = _dev(qweight)
+    _C.ops.gptq_shuffle(dev, _dev(perm), 4)
+    assert np.array_equal(dev.cpu().numpy(), quant.gptq_shuffle(qweight, perm))
+
+
+@pytest.mark.parametrize("group", [32, 128, 512])
+@pytest.mark.parametrize("mode", ["exllama", "exllama_act_order", "plain", "plain_act_order"])
+def test_gptq_dequant_bit_exact(mode, group):
+    from splitwise_amd import _C
+    k, n = 512, 200
+    act = mode.endswith("act_order")
+    qweight, qzeros, scales, g_idx = _gptq_case(k, n, group, 11, act_order=act)
+    if mode.startswith("exllama"):
+        perm = np.argsort(g_idx, kind="stable").astype(np.int32) if act else None
+        w = quant.gptq_shuffle(qweight, perm)
+        idx_dev = _dev(perm) if act else torch.empty((1, 1), device="meta")
+        got = _C.ops.dequant_gptq(_dev(w), _dev(qzeros), _dev(scales), idx_dev, 4, True)
+        ref = quant.gptq_dequant(w, qzeros, scales, perm, True)
+    else:
+        got = _C.ops.dequant_gptq(_dev(qweight), _dev(qzeros), _dev(scales), _dev(g_idx), 4, False)
+        ref = quant.gptq_dequant(qweight, qzeros, scales, g_idx, False)
+    assert np.array_equal(got.cpu().numpy().view(np.uint16), ref.view(np.uint16))
+
+
+GEMM_SHAPES = [          # (M, K, N, group)
+    (1, 128, 128, 128), (1, 2560, 5120, 128), (3, 256, 136, 32), (7, 1024, 520, 64), (8, 5120, 7680, 128),
+    (16, 512, 384, 512), (32, 6912, 1024, 128), (33, 512, 256, 128), (50, 1024, 384, 64), (64, 2048, 1000, 128),
+    (100, 512, 264, 32), (200, 1024, 512, 128), (5, 96, 64, 32), (40, 160, 72, 16),
+]
+
+
+@pytest.mark.parametrize("m,k,n,group", GEMM_SHAPES)
+def test_gptq_gemm_shuffled(m, k, n, group):
+    from splitwise_amd import _C
+    qweight, qzeros, scales, _ = _gptq_case(k, n, group, m + k + n)
+    a = np.random.default_rng(m).standard_normal((m, k)).astype(np.float16)
+    w = quant.gptq_shuffle(qweight)
+    got = _C.ops.gptq_gemm(_dev(a), _dev(w), _dev(qzeros), _dev(scales), torch.empty((1, 1), device="meta"), True, 4)
+    assert got.shape == (m, n) and got.dtype == torch.float16
+    _close(got, quant.gptq_gemm(a, w, qzeros, scales, None, True))
+
+
+@pytest.mark.parametrize("m,k,n,group", [(1, 512, 256, 128), (9, 1024, 520, 64), (48, 512, 128, 32), (70, 512, 136, 128)])
+def test_gptq_gemm_act_order(m, k, n, group):
+    from splitwise_amd import _C
+    qweight, qzeros, scales, g_idx = _gptq_case(k, n, group, 3 * m + k, act_order=True)
+    perm = np.argsort(g_idx, kind="stable").astype(np.int32)
+    a = np.random.default_rng(m).standard_normal((m, k)).astype(np.float16)
+    w = quant.gptq_shuffle(qweight, perm)
+    got = _C.ops.gptq_gemm(_dev(a), _dev(w), _dev(qzeros), _dev(scales), _dev(perm), True, 4)
+    ref = quant.gptq_gemm(a, w, qzeros, scales, perm, True)
+    _close(got, ref)
+    # and the same numbers from the plain-weight path that keeps g_idx
+    got2 = _C.ops.gptq_gemm(_dev(a), _dev(qweight), _dev(qzeros), _dev(scales), _dev(g_idx), False, 4)
+    _close(got2, ref)
+
+
+def test_gptq_gemm_is_reproducible_and_reuses_its_workspace():
+    from splitwise_amd import _C
+    m, k, n, group = 8, 4096, 1024, 128
+    qweight, qzeros, scales, _ = _gptq_case(k, n, group, 77)
+    a = _dev(np.random.default_rng(0).standard_normal((m, k)).astype(np.float16))
+    args = (_dev(quant.gptq_shuffle(qweight)), _dev(qzeros), _dev(scales), None, True, 4)
+    first = _C.ops.gptq_gemm(a, *args)
+    for _ in range(3):
+        assert torch.equal(_C.ops.gptq_gemm(a, *args), first)
+
+
+def test_gptq_large_m_goes_through_reconstruction():
+    from splitwise_amd import _C
+    m, k, n, group = _C.GPTQ_FUSED_MAX_ROWS + 44, 512, 256, 128
+    qweight, qzeros, scales, _ = _gptq_case(k, n, group, 78)
+    a = np.random.default_rng(1).standard_normal((m, k)).astype(np.float16)
+    w = quant.gptq_shuffle(qweight)
+    got = _C.ops.gptq_gemm(_dev(a), _dev(w), _dev(qzeros), _dev(scales), None, True, 4)
+    _close(got, quant.gptq_gemm(a, w, qzeros, scales, None, True))
+
+
+def test_gptq_rejects_other_bit_widths():
+    from splitwise_amd import _C
+    qweight, qzeros, scales, _ = _gptq_case(128, 64, 128, 1)
+    with pytest.raises(RuntimeError, match="4-bit"):
+        _C.ops.gptq_gemm(torch.zeros((1, 256), dtype=torch.float16, device="cuda"), _dev(qweight), _dev(qzeros),
+                         _dev(scales), None, True, 2)
+
+
+# ------------------------------------------------------------------------------------ AWQ
+def _awq_case(k, n, group, seed):
+    rng = np.random.default_rng(seed)
+    q = rng.integers(0, 16, size=(k, n))
+    zeros = rng.integers(0, 16, size=(k // group, n))
+    scales = (rng.uniform(0.5, 1.5, size=(k // group, n)) * 1e-2).astype(np.float16)
+    qweight, qzeros = quant.awq_pack(q, zeros)
+    return qweight, qzeros, scales
+
+
+@pytest.mark.parametrize("k,n,group", [(128, 64, 32), (512, 320, 64), (1024, 1024, 128)])
+def test_awq_dequantize_bit_exact(k, n, group):
+    from splitwise_amd import _C
+    qweight, qzeros, scales = _awq_case(k, n, group, k + n)
+    got = _C.ops.awq_dequantize(_dev(qweight), _dev(scales), _dev(qzeros), 0, 0, 0)
+    ref = quant.awq_dequantize(qweight, scales, qzeros)
+    assert np.array_equal(got.cpu().numpy().view(np.uint16), ref.view(np.uint16))
+
+
+@pytest.mark.parametrize("m,k,n,group", [(1, 128, 128, 128), (1, 2560, 5120, 128), (5, 256, 64, 32), (8, 5120, 7680, 128),
+                                         (17, 1024, 320, 64), (32, 512, 256, 128), (33, 512, 576, 64),
+                                         (100, 1024, 512, 128), (255, 256, 128, 128)])
+def test_awq_gemm(m, k, n, group):
+    from splitwise_amd import _C
+    qweight, qzeros, scales = _awq_case(k, n, group, m + k + n)
+    a = np.random.default_rng(m).standard_normal((m, k)).astype(np.float16)
+    got = _C.ops.awq_gemm(_dev(a), _dev(qweight), _dev(scales), _dev(qzeros), 8)
+    assert got.shape == (m, n) and got.dtype == torch.float16
+    _close(got, quant.awq_gemm(a, qweight, scales, qzeros))
+
+
+def test_awq_argument_checks_mirror_the_reference():
+    from splitwise_amd import _C
+    qweight, qzeros, scales = _awq_case(128, 72, 32, 0)               # N = 72 is not a multiple of 64
+    x = torch.zeros((1, 128), dtype=torch.float16, device="cuda")
+    with pytest.raises(ValueError, match="cta_N"):
+        _C.ops.awq_gemm(x, _dev(qweight), _dev(scales), _dev(qzeros), 8)

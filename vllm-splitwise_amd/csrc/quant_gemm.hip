@@ -1,0 +1,762 @@
+// Weight-only int4 linear layers (GPTQ and AWQ checkpoints) with fp16 activations on gfx950.
+//
+// What it replaces
+//   GPTQ: csrc/quantization/gptq/q_gemm.cu -- gptq_shuffle (:2748-2769, shuffle_exllama_weight
+//         :2032-2093, make_sequential_4bit_kernel :1812-1853, shuffle_4bit_8 qdq_4.cuh:16-35),
+//         gptq_gemm (:2712-2746 -> gemm_half_q_half_cuda :1687-1754), the reconstruct kernels
+//         (:920-1037 shuffled weights, :1517-1561 plain weights + g_idx).
+//   AWQ:  csrc/quantization/awq/gemm_kernels.cu -- awq_gemm (:648-705), awq_dequantize
+//         (:585-640, kernel :274-335), nibble unpack dequantize.cuh:17-84.
+//
+// Value semantics (both formats): W[k][n] = fp16( (q[k][n] - zero[g][n]) * scale[g][n] ) -- the
+// integer difference is exact, the product is rounded once to fp16 exactly as the reference's
+// reconstruct / dequantize kernels do -- and C = A . W with fp32 accumulation on the matrix
+// cores, rounded once to fp16.  GPTQ stores zero - 1 (q_gemm.cu:277), AWQ stores zero.
+//
+// The fused GEMMs are built for the weight-streaming regime (decode, a few to a few hundred
+// rows of A): every int4 word is read from HBM exactly once per 32*MT rows of A, unpacked in
+// registers with the 0x6400 exponent trick and fed straight into v_mfma_f32_32x32x16_f16 as
+// the B operand:
+//   * GPTQ packs 8 consecutive k of one column in a word -- exactly one lane's B fragment.  A
+//     lane loads 16 bytes = 4 adjacent columns, a wave covers 128 columns x 16 k per step, and
+//     column n of MFMA c is n0 + 4*lane + c, so the lane's results are 4 adjacent columns too.
+//   * AWQ packs 8 columns of one k in a word; a wave writes the unpacked 16 k x 256 column
+//     fp16 tile to its private LDS image and gets B fragments back through the transposing
+//     ds_read_b64_tr_b16.
+//   * the 4 waves of a workgroup split the workgroup's k range and add up in LDS; k is split
+//     across workgroups as well, each writing an fp32 partial tile, and the LAST workgroup to
+//     arrive at a tile (counted with one atomic) adds the partials in a fixed order: one
+//     launch, no atomics on data, bitwise reproducible results.
+#include "common.cuh"
+#include <type_traits>
+
+namespace sw {
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+using h2 = __attribute__((ext_vector_type(2))) _Float16;
+using i16x4 = __attribute__((ext_vector_type(4))) short;
+using lds_i16x4_ptr = __attribute__((address_space(3))) i16x4*;
+
+constexpr int kCounterInts = 4096;                  // head of the workspace: one arrival counter per tile
+constexpr int kCounterBytes = kCounterInts * 4;
+constexpr uint32_t kMagic = 0x64006400u;            // half2(1024, 1024)
+
+__device__ __forceinline__ h2 as_h2(uint32_t u) { return __builtin_bit_cast(h2, u); }
+__device__ __forceinline__ uint32_t as_u32(h2 v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ __forceinline__ h2 splat(_Float16 v) { return h2{v, v}; }
+
+// ------------------------------------------------------------------ GPTQ nibble handling
+// A shuffled word holds rows q0 q2 q4 q6 in its low half and q1 q3 q5 q7 in its high half
+// (qdq_4.cuh:12-14), so masking with 0x000f000f pairs rows (0,1), with 0x00f000f0 rows (2,3)
+// scaled by 16, and the same again after a shift by 8.
+struct GptqCol {
+  h2 z1;     // -(1024 + zero)
+  h2 z16;    // -(64 + zero)
+  h2 s;      // scale, both halves
+};
+
+__device__ __forceinline__ GptqCol gptq_col(uint32_t zero, uint16_t scale_bits) {
+  GptqCol c;
+  const uint32_t zb = 0xe400u | zero;               // -(1024 + zero) for zero <= 16
+  c.z1 = as_h2(zb | (zb << 16));
+  c.z16 = splat((_Float16)(-64 - (int)zero));
+  c.s = as_h2((uint32_t)scale_bits | ((uint32_t)scale_bits << 16));
+  return c;
+}
+
+// 8 rows of one column -> fp16 weights in row order (4 dwords = one MFMA B fragment)
+__device__ __forceinline__ f16x8 gptq_dequant8(uint32_t w, const GptqCol& col) {
+  const h2 y16 = splat((_Float16)0.0625f);
+  const h2 q0 = as_h2((w & 0x000f000fu) | kMagic);
+  const h2 q1 = as_h2((w & 0x00f000f0u) | kMagic);
+  w >>= 8;
+  const h2 q2 = as_h2((w & 0x000f000fu) | kMagic);
+  const h2 q3 = as_h2((w & 0x00f000f0u) | kMagic);
+  const h2 d0 = (q0 + col.z1) * col.s;
+  const h2 d1 = (q1 * y16 + col.z16) * col.s;
+  const h2 d2 = (q2 + col.z1) * col.s;
+  const h2 d3 = (q3 * y16 + col.z16) * col.s;
+  union { uint32_t u[4]; f16x8 f; } r;
+  r.u[0] = as_u32(d0); r.u[1] = as_u32(d1); r.u[2] = as_u32(d2); r.u[3] = as_u32(d3);
+  return r.f;
+}
+
+__device__ __forceinline__ uint32_t shuffle_nibbles(uint32_t qa) {
+  uint32_t qb = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const uint32_t even = qa & 0x0fu, odd = (qa & 0xf0u) >> 4;
+    qa >>= 8;
+    qb |= odd << (4 * i + 16);
+    qb |= even << (4 * i);
+  }
+  return qb;
+}
+
+// ------------------------------------------------------------------ shared GEMM epilogue
+// acc[t][c][r] <-> row m0 + 32t + 8(r>>2) + 4*half + (r&3), column ncol + c.
+// Adds the four waves' accumulators through LDS (two passes of 8 accumulator rows), then either
+// stores fp16 or hands the fp32 tile to the cross-workgroup reduction.
+template <int MT, int NC>
+__device__ __forceinline__ void reduce_and_store(f32x16 (&acc)[MT][NC], float* red, uint16_t* c, int M, int N,
+                                                 int m0, int ncol0, int col_step, int ksplit, float* partials,
+                                                 int32_t* counters, int tile) {
+  // red: [wave 4][t MT][c NC][r8 8][lane 64]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int half = lane >> 5;
+  __shared__ int s_last;
+  float sum[2][MT][NC][2];                            // [pass][t][c][which of this wave's two rows]
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+      for (int cc = 0; cc < NC; ++cc)
+#pragma unroll
+        for (int r8 = 0; r8 < 8; ++r8)
+          red[(((wave * MT + t) * NC + cc) * 8 + r8) * 64 + lane] = acc[t][cc][8 * pass + r8];
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+      for (int cc = 0; cc < NC; ++cc)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const int r8 = wave + 4 * e;
+          float v = 0.f;
+#pragma unroll
+          for (int w = 0; w < 4; ++w) v += red[(((w * MT + t) * NC + cc) * 8 + r8) * 64 + lane];
+          sum[pass][t][cc][e] = v;
+        }
+  }
+  // this thread now owns rows r = 8*pass + wave + 4e  ->  m = m0 + 32t + 16*pass + 8e + 4*half + wave
+  bool last = true;
+  if (ksplit > 1) {
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass)
+#pragma unroll
+      for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const int m = m0 + 32 * t + 16 * pass + 8 * e + 4 * half + wave;
+          if (m >= M) continue;
+#pragma unroll
+          for (int g4 = 0; g4 < NC / 4; ++g4) {
+            const int n = ncol0 + g4 * col_step;
+            if (n >= N) continue;
+            float4 v = make_float4(sum[pass][t][4 * g4][e], sum[pass][t][4 * g4 + 1][e], sum[pass][t][4 * g4 + 2][e],
+                                   sum[pass][t][4 * g4 + 3][e]);
+            *reinterpret_cast<float4*>(partials + ((size_t)blockIdx.z * M + m) * N + n) = v;
+          }
+        }
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = (atomicAdd(&counters[tile], 1) == ksplit - 1);
+    __syncthreads();
+    last = s_last != 0;
+    if (last) __threadfence();
+  }
+  if (!last) return;
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass)
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int m = m0 + 32 * t + 16 * pass + 8 * e + 4 * half + wave;
+        if (m >= M) continue;
+#pragma unroll
+        for (int g4 = 0; g4 < NC / 4; ++g4) {
+          const int n = ncol0 + g4 * col_step;
+          if (n >= N) continue;
+          float4 v;
+          if (ksplit > 1) {
+            v = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int z = 0; z < ksplit; ++z) {          // fixed order: reproducible
+              const float4 p = *reinterpret_cast<const float4*>(partials + ((size_t)z * M + m) * N + n);
+              v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+            }
+          } else {
+            v = make_float4(sum[pass][t][4 * g4][e], sum[pass][t][4 * g4 + 1][e], sum[pass][t][4 * g4 + 2][e],
+                            sum[pass][t][4 * g4 + 3][e]);
+          }
+          uint2 o;
+          o.x = (uint32_t)float_to_f16_bits(v.x) | ((uint32_t)float_to_f16_bits(v.y) << 16);
+          o.y = (uint32_t)float_to_f16_bits(v.z) | ((uint32_t)float_to_f16_bits(v.w) << 16);
+          *reinterpret_cast<uint2*>(c + (size_t)m * N + n) = o;
+        }
+      }
+  if (ksplit > 1 && threadIdx.x == 0) counters[tile] = 0;   // ready for the next call
+}
+
+// ------------------------------------------------------------------ GPTQ fused GEMM
+// grid (column tiles of 128, row tiles of 32*MT, k splits); 4 waves, each owning a contiguous
+// run of "units" of U k-steps (16 k each).  group_size must be a multiple of 16*U.
+template <int MT, int U>
+__global__ void __launch_bounds__(256)
+gptq_gemm_kernel(uint16_t* __restrict__ c, const uint16_t* __restrict__ a, const uint32_t* __restrict__ qweight,
+                 const uint32_t* __restrict__ qzeros, const uint16_t* __restrict__ scales, int M, int N, int K,
+                 int group_size, int ksplit, float* __restrict__ partials, int32_t* __restrict__ counters) {
+  extern __shared__ __attribute__((aligned(16))) float red[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 31, half = lane >> 5;
+  const int n0 = blockIdx.x * 128;
+  const int ncol = n0 + 4 * j;
+  const bool col_ok = ncol < N;
+  const int ncl = col_ok ? ncol : 0;                  // clamped column for loads
+  const int m0 = blockIdx.y * 32 * MT;
+
+  const int units = K / (16 * U);
+  const int nw = ksplit * 4, wg = blockIdx.z * 4 + wave;
+  const int u_begin = (int)((int64_t)units * wg / nw), u_end = (int)((int64_t)units * (wg + 1) / nw);
+
+  f32x16 acc[MT][4];
+#pragma unroll
+  for (int t = 0; t < MT; ++t)
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][cc][r] = 0.f;
+
+  const uint16_t* ap[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) ap[t] = a + (size_t)min(m0 + 32 * t + j, M - 1) * K + 8 * half;
+  const uint32_t* wp = qweight + (size_t)half * N + ncl;
+  const int zshift = 16 * (j & 1);                    // this lane's 4 zero nibbles inside the zeros word
+
+  uint4 wq[2][U];
+  f16x8 af[2][U][MT];
+  uint32_t zq = 0;                                    // zeros word / scales of the NEXT group to set up
+  uint2 sq = make_uint2(0, 0);
+  GptqCol col[4];
+  int cur_group = -1;
+
+  // BUF is a compile-time constant so that the double buffers stay in registers
+  auto load_unit = [&](auto BUF, int u) {
+    constexpr int buf = decltype(BUF)::value;
+#pragma unroll
+    for (int s = 0; s < U; ++s) {
+      const int step = u * U + s;
+      wq[buf][s] = *reinterpret_cast<const uint4*>(wp + (size_t)(2 * step) * N);
+#pragma unroll
+      for (int t = 0; t < MT; ++t) af[buf][s][t] = *reinterpret_cast<const f16x8*>(ap[t] + 16 * step);
+    }
+  };
+  auto load_group = [&](int g) {
+    zq = qzeros[(size_t)g * (N / 8) + ncl / 8];
+    sq = *reinterpret_cast<const uint2*>(scales + (size_t)g * N + ncl);
+  };
+  auto run_unit = [&](auto BUF, int u) {
+    constexpr int buf = decltype(BUF)::value;
+    const int g = u * 16 * U / group_size;
+    if (g != cur_group) {                             // wave-uniform
+      const uint32_t z = zq >> zshift;
+      col[0] = gptq_col((z & 0xfu) + 1, (uint16_t)(sq.x & 0xffffu));
+      col[1] = gptq_col(((z >> 4) & 0xfu) + 1, (uint16_t)(sq.x >> 16));
+      col[2] = gptq_col(((z >> 8) & 0xfu) + 1, (uint16_t)(sq.y & 0xffffu));
+      col[3] = gptq_col(((z >> 12) & 0xfu) + 1, (uint16_t)(sq.y >> 16));
+      cur_group = g;
+    }
+    if (u + 1 < u_end) {                              // next unit's loads fly during this unit's math
+      load_unit(std::integral_constant<int, buf ^ 1>{}, u + 1);
+      const int gn = (u + 1) * 16 * U / group_size;
+      if (gn != g) load_group(gn);
+    }
+#pragma unroll
+    for (int s = 0; s < U; ++s) {
+      const uint4 w = wq[buf][s];
+      const f16x8 b0 = gptq_dequant8(w.x, col[0]);
+      const f16x8 b1 = gptq_dequant8(w.y, col[1]);
+      const f16x8 b2 = gptq_dequant8(w.z, col[2]);
+      const f16x8 b3 = gptq_dequant8(w.w, col[3]);
+#pragma unroll
+      for (int t = 0; t < MT; ++t) {
+        acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[buf][s][t], b0, acc[t][0], 0, 0, 0);
+        acc[t][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[buf][s][t], b1, acc[t][1], 0, 0, 0);
+        acc[t][2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[buf][s][t], b2, acc[t][2], 0, 0, 0);
+        acc[t][3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[buf][s][t], b3, acc[t][3], 0, 0, 0);
+      }
+    }
+  };
+
+  if (u_begin < u_end) {
+    load_unit(std::integral_constant<int, 0>{}, u_begin);
+    load_group(u_begin * 16 * U / group_size);
+  }
+  for (int u = u_begin; u < u_end; u += 2) {
+    run_unit(std::integral_constant<int, 0>{}, u);
+    if (u + 1 < u_end) run_unit(std::integral_constant<int, 1>{}, u + 1);
+  }
+  reduce_and_store<MT, 4>(acc, red, c, M, N, m0, ncol, 0, ksplit, partials, counters,
+                          blockIdx.y * gridDim.x + blockIdx.x);
+}
+
+// ------------------------------------------------------------------ GPTQ, plain (unshuffled) weights + g_idx
+// The slow, always-correct path of gemm_half_q_half_alt (q_gemm.cu:1288-1383): rows may belong
+// to any group.  64 columns x 4 k-slices per workgroup, up to 8 rows of A per pass.
+__global__ void __launch_bounds__(256)
+gptq_alt_gemm_kernel(uint16_t* __restrict__ c, const uint16_t* __restrict__ a, const uint32_t* __restrict__ qweight,
+                     const uint32_t* __restrict__ qzeros, const uint16_t* __restrict__ scales,
+                     const int32_t* __restrict__ g_idx, int M, int N, int K) {
+  __shared__ float red[4][8][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int n = blockIdx.x * 64 + tx;
+  const int m0 = blockIdx.y * 8;
+  const int rows = min(8, M - m0);
+  float acc[8];
+#pragma unroll
+  for (int m = 0; m < 8; ++m) acc[m] = 0.f;
+  if (n < N) {
+    const int zsh = 4 * (n & 7);
+    for (int r = ty; r < K / 8; r += 4) {
+      const uint32_t w = qweight[(size_t)r * N + n];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int k = 8 * r + i;
+        const int g = g_idx[k];
+        const int zero = (int)((qzeros[(size_t)g * (N / 8) + n / 8] >> zsh) & 0xfu) + 1;
+        const _Float16 s = __builtin_bit_cast(_Float16, scales[(size_t)g * N + n]);
+        const float wv = (float)((_Float16)((int)((w >> (4 * i)) & 0xfu) - zero) * s);
+        for (int m = 0; m < rows; ++m) acc[m] += f16_bits_to_float(a[(size_t)(m0 + m) * K + k]) * wv;
+      }
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < 8; ++m) red[ty][m][tx] = acc[m];
+  __syncthreads();
+  if (n < N)
+    for (int m = ty; m < rows; m += 4) {
+      const float v = red[0][m][tx] + red[1][m][tx] + red[2][m][tx] + red[3][m][tx];
+      c[(size_t)(m0 + m) * N + n] = float_to_f16_bits(v);
+    }
+}
+
+// ------------------------------------------------------------------ GPTQ helpers
+__global__ void gptq_shuffle_kernel(uint32_t* __restrict__ dst, const uint32_t* __restrict__ src,
+                                    const int32_t* __restrict__ q_perm, int word_rows, int N) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)word_rows * N) return;
+  const int r = (int)(idx / N), n = (int)(idx - (int64_t)r * N);
+  uint32_t w;
+  if (q_perm) {                                       // gather the 8 source rows of this word first
+    w = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int srow = q_perm[8 * r + i];
+      const uint32_t sw = src[(size_t)(srow >> 3) * N + n];
+      w |= ((sw >> (4 * (srow & 7))) & 0xfu) << (4 * i);
+    }
+  } else {
+    w = src[idx];
+  }
+  dst[idx] = shuffle_nibbles(w);
+}
+
+__global__ void permute_columns_kernel(uint16_t* __restrict__ dst, const uint16_t* __restrict__ src,
+                                       const int32_t* __restrict__ perm, int M, int K) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)M * K) return;
+  const int m = (int)(idx / K), k = (int)(idx - (int64_t)m * K);
+  dst[idx] = src[(size_t)m * K + perm[k]];
+}
+
+// one thread: one word row x 4 columns -> 8 rows x 4 fp16
+__global__ void gptq_dequant_kernel(uint16_t* __restrict__ out, const uint32_t* __restrict__ qweight,
+                                    const uint32_t* __restrict__ qzeros, const uint16_t* __restrict__ scales,
+                                    const int32_t* __restrict__ g_idx, int K, int N, int group_size, int shuffled) {
+  const int n4 = N / 4;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)(K / 8) * n4) return;
+  const int r = (int)(idx / n4), n = 4 * (int)(idx - (int64_t)r * n4);
+  const uint4 w4 = *reinterpret_cast<const uint4*>(qweight + (size_t)r * N + n);
+  const uint32_t w[4] = {w4.x, w4.y, w4.z, w4.w};
+  if (shuffled) {
+    const int g = 8 * r / group_size;
+    const uint32_t z = qzeros[(size_t)g * (N / 8) + n / 8] >> (4 * (n & 7));
+    const uint2 s = *reinterpret_cast<const uint2*>(scales + (size_t)g * N + n);
+    const uint16_t sb[4] = {(uint16_t)(s.x & 0xffffu), (uint16_t)(s.x >> 16), (uint16_t)(s.y & 0xffffu),
+                            (uint16_t)(s.y >> 16)};
+    union { f16x8 f; uint32_t u[4]; } d[4];
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) d[cc].f = gptq_dequant8(w[cc], gptq_col(((z >> (4 * cc)) & 0xfu) + 1, sb[cc]));
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int row = g_idx ? g_idx[8 * r + i] : 8 * r + i;     // g_idx holds the row permutation here
+      const int sh = 16 * (i & 1);
+      uint2 o;
+      o.x = ((d[0].u[i >> 1] >> sh) & 0xffffu) | (((d[1].u[i >> 1] >> sh) & 0xffffu) << 16);
+      o.y = ((d[2].u[i >> 1] >> sh) & 0xffffu) | (((d[3].u[i >> 1] >> sh) & 0xffffu) << 16);
+      *reinterpret_cast<uint2*>(out + (size_t)row * N + n) = o;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int k = 8 * r + i;
+      const int g = g_idx ? g_idx[k] : k / group_size;
+      const uint32_t z = qzeros[(size_t)g * (N / 8) + n / 8] >> (4 * (n & 7));
+      uint16_t o[4];
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) {
+        const int zero = (int)((z >> (4 * cc)) & 0xfu) + 1;
+        const _Float16 s = __builtin_bit_cast(_Float16, scales[(size_t)g * N + n + cc]);
+        o[cc] = __builtin_bit_cast(uint16_t, (_Float16)((_Float16)((int)((w[cc] >> (4 * i)) & 0xfu) - zero) * s));
+      }
+      uint2 ov;
+      ov.x = o[0] | ((uint32_t)o[1] << 16);
+      ov.y = o[2] | ((uint32_t)o[3] << 16);
+      *reinterpret_cast<uint2*>(out + (size_t)k * N + n) = ov;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ AWQ
+// A word holds 8 output columns of one input row; masking pairs nibbles (0,4) (1,5) (2,6) (3,7),
+// and checkpoints are packed so that those pairs ARE logical columns (0,1) (2,3) (4,5) (6,7)
+// (dequantize.cuh:40-56).
+struct AwqCols {
+  h2 z1[2];    // -(1024 + zero) for column pairs (0,1) and (4,5)
+  h2 z16[2];   // -(64 + zero) for column pairs (2,3) and (6,7)
+  h2 s[4];     // scales of column pairs (0,1) (2,3) (4,5) (6,7)
+};
+
+__device__ __forceinline__ AwqCols awq_cols(uint32_t zw, uint4 sc) {
+  const h2 neg16th = splat((_Float16)(-0.0625f));
+  AwqCols c;
+  c.z1[0] = as_h2(((zw & 0x000f000fu) | kMagic) ^ 0x80008000u);
+  c.z16[0] = as_h2((zw & 0x00f000f0u) | kMagic) * neg16th;
+  zw >>= 8;
+  c.z1[1] = as_h2(((zw & 0x000f000fu) | kMagic) ^ 0x80008000u);
+  c.z16[1] = as_h2((zw & 0x00f000f0u) | kMagic) * neg16th;
+  c.s[0] = as_h2(sc.x); c.s[1] = as_h2(sc.y); c.s[2] = as_h2(sc.z); c.s[3] = as_h2(sc.w);
+  return c;
+}
+
+// one word -> 8 fp16 in logical column order
+__device__ __forceinline__ uint4 awq_dequant8(uint32_t w, const AwqCols& c) {
+  const h2 y16 = splat((_Float16)0.0625f);
+  const h2 q0 = as_h2((w & 0x000f000fu) | kMagic);
+  const h2 q1 = as_h2((w & 0x00f000f0u) | kMagic);
+  w >>= 8;
+  const h2 q2 = as_h2((w & 0x000f000fu) | kMagic);
+  const h2 q3 = as_h2((w & 0x00f000f0u) | kMagic);
+  uint4 r;
+  r.x = as_u32((q0 + c.z1[0]) * c.s[0]);
+  r.y = as_u32((q1 * y16 + c.z16[0]) * c.s[1]);
+  r.z = as_u32((q2 + c.z1[1]) * c.s[2]);
+  r.w = as_u32((q3 * y16 + c.z16[1]) * c.s[3]);
+  return r;
+}
+
+__global__ void awq_dequantize_kernel(uint16_t* __restrict__ out, const uint32_t* __restrict__ qweight,
+                                      const uint16_t* __restrict__ scales, const uint32_t* __restrict__ qzeros,
+                                      int K, int N, int group_size) {
+  const int nw = N / 8;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)K * nw) return;
+  const int k = (int)(idx / nw), wc = (int)(idx - (int64_t)k * nw);
+  const int g = k / group_size;
+  const AwqCols cols = awq_cols(qzeros[(size_t)g * nw + wc],
+                                *reinterpret_cast<const uint4*>(scales + (size_t)g * N + 8 * wc));
+  *reinterpret_cast<uint4*>(out + (size_t)k * N + 8 * wc) = awq_dequant8(qweight[idx], cols);
+}
+
+// grid (column tiles of 256, row tiles of 32, k splits); 4 waves each owning a run of 16-k steps.
+// LDS per wave: 16 rows x (512 + 16) bytes image; the reduction buffer reuses the same memory.
+constexpr int kAwqRow = 512 + 16;                   // bytes per image row (pad: rows land on different banks)
+constexpr int kAwqImage = 16 * kAwqRow;
+
+__global__ void __launch_bounds__(256)
+awq_gemm_kernel(uint16_t* __restrict__ c, const uint16_t* __restrict__ a, const uint32_t* __restrict__ qweight,
+                const uint16_t* __restrict__ scales, const uint32_t* __restrict__ qzeros, int M, int N, int K,
+                int group_size, int ksplit, float* __restrict__ partials, int32_t* __restrict__ counters) {
+  extern __shared__ __attribute__((aligned(16))) float red[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 31, half = lane >> 5;
+  char* image = reinterpret_cast<char*>(red) + wave * kAwqImage;
+  const int nw = N / 8;
+  const int n0 = blockIdx.x * 256;
+  const int wcol = n0 / 8 + j;                        // this lane's word column when loading
+  const bool w_ok = wcol < nw;
+  const int wcl = w_ok ? wcol : 0;
+  const int m0 = blockIdx.y * 32;
+
+  const int steps = K / 16;
+  const int nwv = ksplit * 4, wg = blockIdx.z * 4 + wave;
+  const int s_begin = (int)((int64_t)steps * wg / nwv), s_end = (int)((int64_t)steps * (wg + 1) / nwv);
+
+  f32x16 acc[1][8];
+#pragma unroll
+  for (int cb = 0; cb < 8; ++cb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[0][cb][r] = 0.f;
+
+  const uint16_t* ap = a + (size_t)min(m0 + j, M - 1) * K + 8 * half;
+  // transposing read: lane 4q+p of a 16-lane group supplies row q, columns 4p..4p+3 of a
+  // 4 x 16 block and receives rows 0..3 of column (lane & 15); groups 0,1 serve k 0..7 and
+  // groups 2,3 serve k 8..15 of columns 0..15 / 16..31 of a 32-column block.
+  const int tr_q = (lane & 15) >> 2, tr_p = lane & 3, tr_g = lane >> 4;
+  const int tr_off = (8 * (tr_g >> 1) + tr_q) * kAwqRow + (16 * (tr_g & 1) + 4 * tr_p) * 2;
+
+  AwqCols cols;
+  int cur_group = -1;
+  uint32_t wq[2][8];
+  f16x8 af[2];
+  auto load_step = [&](auto BUF, int s) {
+    constexpr int buf = decltype(BUF)::value;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) wq[buf][t] = qweight[(size_t)(16 * s + 2 * t + half) * nw + wcl];
+    af[buf] = *reinterpret_cast<const f16x8*>(ap + 16 * s);
+  };
+  auto run_step = [&](auto BUF, int s) {
+    constexpr int buf = decltype(BUF)::value;
+    const int g = 16 * s / group_size;
+    if (g != cur_group) {                             // wave-uniform; group data is L2-resident
+      cols = awq_cols(qzeros[(size_t)g * nw + wcl], *reinterpret_cast<const uint4*>(scales + (size_t)g * N + 8 * wcl));
+      cur_group = g;
+    }
+    if (s + 1 < s_end) load_step(std::integral_constant<int, buf ^ 1>{}, s + 1);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      uint4 d = awq_dequant8(wq[buf][t], cols);
+      if (!w_ok) d = make_uint4(0, 0, 0, 0);
+      *reinterpret_cast<uint4*>(image + (2 * t + half) * kAwqRow + 16 * j) = d;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#pragma unroll
+    for (int cb = 0; cb < 8; ++cb) {
+      const char* base = image + tr_off + cb * 64;
+      const i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_i16x4_ptr)(base));
+      const i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_i16x4_ptr)(base + 4 * kAwqRow));
+      union { struct { i16x4 a, b; } p; f16x8 f; } bf;
+      bf.p.a = lo;
+      bf.p.b = hi;
+      acc[0][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[buf], bf.f, acc[0][cb], 0, 0, 0);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");    // the image is rewritten next step
+  };
+  if (s_begin < s_end) load_step(std::integral_constant<int, 0>{}, s_begin);
+  for (int s = s_begin; s < s_end; s += 2) {
+    run_step(std::integral_constant<int, 0>{}, s);
+    if (s + 1 < s_end) run_step(std::integral_constant<int, 1>{}, s + 1);
+  }
+  // accumulator cb holds column n0 + 32*cb + j; the four waves' sums meet in LDS (which reuses
+  // the image memory) in four passes of 4 accumulator rows each.
+  __syncthreads();
+  float* buf = red;
+  const int tile = blockIdx.y * gridDim.x + blockIdx.x;
+  __shared__ int s_last;
+  float sum[4][8];                                    // [pass][cb]: row r = 4*pass + wave
+#pragma unroll
+  for (int pass = 0; pass < 4; ++pass) {
+    __syncthreads();
+#pragma unroll
+    for (int cb = 0; cb < 8; ++cb)
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) buf[((wave * 8 + cb) * 4 + r4) * 64 + lane] = acc[0][cb][4 * pass + r4];
+    __syncthreads();
+#pragma unroll
+    for (int cb = 0; cb < 8; ++cb) {
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) v += buf[((w * 8 + cb) * 4 + wave) * 64 + lane];
+      sum[pass][cb] = v;
+    }
+  }
+  // this thread owns row m0 + 8*pass + 4*half + wave, columns n0 + 32*cb + j
+  bool last = true;
+  if (ksplit > 1) {
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+      const int m = m0 + 8 * pass + 4 * half + wave;
+      if (m >= M) continue;
+#pragma unroll
+      for (int cb = 0; cb < 8; ++cb) {
+        const int n = n0 + 32 * cb + j;
+        if (n < N) partials[((size_t)blockIdx.z * M + m) * N + n] = sum[pass][cb];
+      }
+    }
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = (atomicAdd(&counters[tile], 1) == ksplit - 1);
+    __syncthreads();
+    last = s_last != 0;
+    if (last) __threadfence();
+  }
+  if (!last) return;
+#pragma unroll
+  for (int pass = 0; pass < 4; ++pass) {
+    const int m = m0 + 8 * pass + 4 * half + wave;
+    if (m >= M) continue;
+#pragma unroll
+    for (int cb = 0; cb < 8; ++cb) {
+      const int n = n0 + 32 * cb + j;
+      if (n >= N) continue;
+      float v = sum[pass][cb];
+      if (ksplit > 1) {
+        v = 0.f;
+        for (int z = 0; z < ksplit; ++z) v += partials[((size_t)z * M + m) * N + n];
+      }
+      c[(size_t)m * N + n] = float_to_f16_bits(v);
+    }
+  }
+  if (ksplit > 1 && threadIdx.x == 0) counters[tile] = 0;
+}
+
+// how many ways to split k across workgroups: aim at two workgroups per compute unit, keep at
+// least `min_units` units of work per wave, and stay inside the workspace
+int pick_ksplit(int tiles, int units, int min_units, int M, int N, int64_t workspace_bytes) {
+  if (tiles > kCounterInts) return 1;
+  int ks = (512 + tiles - 1) / tiles;
+  const int cap = units / (4 * min_units);
+  if (ks > cap) ks = cap;
+  if (ks > 64) ks = 64;
+  const int64_t per_split = (int64_t)M * N * 4;
+  const int64_t room = (workspace_bytes - kCounterBytes) / (per_split > 0 ? per_split : 1);
+  if (ks > room) ks = (int)room;
+  return ks < 1 ? 1 : ks;
+}
+
+}  // namespace
+}  // namespace sw
+
+using namespace sw;
+
+extern "C" {
+
+int64_t sw_quant_gemm_workspace_bytes(int M, int N, int K) {
+  // counters + up to 8 fp32 partial tiles (fewer splits are used when this is smaller than
+  // what the heuristic would like) + a permuted copy of A for act-order GPTQ
+  const int64_t partial = (int64_t)M * N * 4;
+  return kCounterBytes + 8 * partial + (int64_t)M * K * 2 + 256;
+}
+
+int sw_gptq_shuffle(uint32_t* qweight, const int32_t* q_perm, int K, int N, int bit, void* scratch, void* stream) {
+  SW_CHECK_ARG(bit == 4, "gptq_shuffle: only 4-bit weights are supported (got %d)", bit);
+  SW_CHECK_ARG(K > 0 && N > 0 && K % 8 == 0, "gptq_shuffle: bad shape K=%d N=%d", K, N);
+  SW_CHECK_ARG(q_perm == nullptr || scratch != nullptr, "gptq_shuffle: a row permutation needs a scratch buffer");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int64_t words = (int64_t)(K / 8) * N;
+  const int blocks = (int)((words + 255) / 256);
+  if (q_perm) {
+    uint32_t* tmp = static_cast<uint32_t*>(scratch);
+    hipLaunchKernelGGL(gptq_shuffle_kernel, dim3(blocks), dim3(256), 0, st, tmp, qweight, q_perm, K / 8, N);
+    SW_CHECK_LAUNCH();
+    SW_CHECK_HIP(hipMemcpyAsync(qweight, tmp, words * 4, hipMemcpyDeviceToDevice, st));
+  } else {
+    hipLaunchKernelGGL(gptq_shuffle_kernel, dim3(blocks), dim3(256), 0, st, qweight, qweight, nullptr, K / 8, N);
+    SW_CHECK_LAUNCH();
+  }
+  return SW_OK;
+}
+
+int sw_gptq_dequant(void* out, const uint32_t* qweight, const uint32_t* qzeros, const void* scales,
+                    const int32_t* g_idx, int K, int N, int groups, int use_exllama, int bit, void* stream) {
+  SW_CHECK_ARG(bit == 4, "gptq_dequant: only 4-bit weights are supported (got %d)", bit);
+  SW_CHECK_ARG(K > 0 && N > 0 && groups > 0 && K % 8 == 0 && N % 8 == 0 && K % groups == 0,
+               "gptq_dequant: bad shape K=%d N=%d groups=%d", K, N, groups);
+  SW_CHECK_ARG(use_exllama || g_idx != nullptr, "gptq_dequant: plain weights need g_idx");
+  const int group_size = K / groups;
+  SW_CHECK_ARG(!use_exllama || group_size % 8 == 0, "gptq_dequant: group size %d is not a multiple of 8", group_size);
+  const int64_t threads = (int64_t)(K / 8) * (N / 4);
+  hipLaunchKernelGGL(gptq_dequant_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), static_cast<uint16_t*>(out), qweight, qzeros,
+                     static_cast<const uint16_t*>(scales), g_idx, K, N, group_size, use_exllama ? 1 : 0);
+  SW_CHECK_LAUNCH();
+  return SW_OK;
+}
+
+int sw_gptq_gemm(void* c, const void* a, const uint32_t* qweight, const uint32_t* qzeros, const void* scales,
+                 const int32_t* g_idx, int M, int N, int K, int groups, int use_exllama, int bit, void* workspace,
+                 int64_t workspace_bytes, void* stream) {
+  SW_CHECK_ARG(bit == 4, "gptq_gemm: only 4-bit weights are supported (got %d)", bit);
+  SW_CHECK_ARG(M >= 0 && N > 0 && K > 0 && groups > 0 && K % 32 == 0 && N % 8 == 0 && K % groups == 0,
+               "gptq_gemm: bad shape M=%d N=%d K=%d groups=%d", M, N, K, groups);
+  if (M == 0) return SW_OK;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  uint16_t* cp = static_cast<uint16_t*>(c);
+  const uint16_t* ap = static_cast<const uint16_t*>(a);
+  const uint16_t* sp = static_cast<const uint16_t*>(scales);
+  if (!use_exllama) {
+    SW_CHECK_ARG(g_idx != nullptr, "gptq_gemm: plain (unshuffled) weights need g_idx");
+    hipLaunchKernelGGL(gptq_alt_gemm_kernel, dim3((N + 63) / 64, (M + 7) / 8), dim3(256), 0, st, cp, ap, qweight,
+                       qzeros, sp, g_idx, M, N, K);
+    SW_CHECK_LAUNCH();
+    return SW_OK;
+  }
+  const int group_size = K / groups;
+  SW_CHECK_ARG(group_size % 16 == 0, "gptq_gemm: group size %d is not a multiple of 16", group_size);
+  SW_CHECK_ARG(workspace != nullptr && workspace_bytes >= kCounterBytes,
+               "gptq_gemm: workspace of at least %d bytes required", kCounterBytes);
+  int32_t* counters = static_cast<int32_t*>(workspace);
+  char* ws = static_cast<char*>(workspace);
+  int64_t avail = workspace_bytes;
+  if (g_idx) {                                        // act-order: A's columns follow the shuffled row order
+    const int64_t abytes = ((int64_t)M * K * 2 + 255) / 256 * 256;
+    SW_CHECK_ARG(workspace_bytes >= kCounterBytes + abytes, "gptq_gemm: workspace too small for the permuted input");
+    avail -= abytes;
+    uint16_t* a_perm = reinterpret_cast<uint16_t*>(ws + avail);
+    const int64_t total = (int64_t)M * K;
+    hipLaunchKernelGGL(permute_columns_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a_perm, ap,
+                       g_idx, M, K);
+    SW_CHECK_LAUNCH();
+    ap = a_perm;
+  }
+  float* partials = reinterpret_cast<float*>(ws + kCounterBytes);
+  const bool wide = (group_size % 64 == 0) && (K % 64 == 0);
+  const int mt = M > 32 ? 2 : 1;
+  const int u = !wide ? 1 : (mt == 1 ? 4 : 2);
+  const int col_tiles = (N + 127) / 128, row_tiles = (M + 32 * mt - 1) / (32 * mt);
+  const int ks = pick_ksplit(col_tiles * row_tiles, K / (16 * u), 2, M, N, avail);
+  const dim3 grid(col_tiles, row_tiles, ks);
+  const size_t lds = (size_t)4 * mt * 4 * 8 * 64 * 4;
+#define SW_GPTQ_LAUNCH(MT_, U_)                                                                             \
+  hipLaunchKernelGGL((gptq_gemm_kernel<MT_, U_>), grid, dim3(256), lds, st, cp, ap, qweight, qzeros, sp, M, N, K, \
+                     group_size, ks, partials, counters)
+  if (mt == 1 && u == 4) SW_GPTQ_LAUNCH(1, 4);
+  else if (mt == 2 && u == 2) SW_GPTQ_LAUNCH(2, 2);
+  else if (mt == 1) SW_GPTQ_LAUNCH(1, 1);
+  else SW_GPTQ_LAUNCH(2, 1);
+#undef SW_GPTQ_LAUNCH
+  SW_CHECK_LAUNCH();
+  return SW_OK;
+}
+
+int sw_awq_dequantize(void* out, const uint32_t* qweight, const void* scales, const uint32_t* qzeros, int K, int N,
+                      int group_size, void* stream) {
+  SW_CHECK_ARG(K > 0 && N > 0 && N % 8 == 0 && group_size > 0 && K % group_size == 0,
+               "awq_dequantize: bad shape K=%d N=%d group=%d", K, N, group_size);
+  const int64_t threads = (int64_t)K * (N / 8);
+  hipLaunchKernelGGL(awq_dequantize_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), static_cast<uint16_t*>(out), qweight,
+                     static_cast<const uint16_t*>(scales), qzeros, K, N, group_size);
+  SW_CHECK_LAUNCH();
+  return SW_OK;
+}
+
+int sw_awq_gemm(void* c, const void* a, const uint32_t* qweight, const void* scales, const uint32_t* qzeros, int M,
+                int K, int N, int group_size, void* workspace, int64_t workspace_bytes, void* stream) {
+  // the reference's argument checks (gemm_kernels.cu:671-678)
+  SW_CHECK_ARG(N % 64 == 0, "OC is not multiple of cta_N = 64");
+  SW_CHECK_ARG(group_size > 0 && group_size % 32 == 0, "Group size should be a multiple of 32");
+  SW_CHECK_ARG(N % group_size == 0, "OC is not multiple of Group size");
+  SW_CHECK_ARG(M >= 0 && K > 0 && K % group_size == 0, "awq_gemm: bad shape M=%d K=%d group=%d", M, K, group_size);
+  if (M == 0) return SW_OK;
+  SW_CHECK_ARG(workspace != nullptr && workspace_bytes >= kCounterBytes,
+               "awq_gemm: workspace of at least %d bytes required", kCounterBytes);
+  int32_t* counters = static_cast<int32_t*>(workspace);
+  float* partials = reinterpret_cast<float*>(static_cast<char*>(workspace) + kCounterBytes);
+  const int col_tiles = (N + 255) / 256, row_tiles = (M + 31) / 32;
+  const int ks = pick_ksplit(col_tiles * row_tiles, K / 16, 4, M, N, workspace_bytes);
+  const size_t lds = (size_t)4 * kAwqImage;           // four wave images; the reduction buffer reuses them
+  static_assert(4 * 8 * 4 * 64 * 4 <= 4 * kAwqImage, "the reduction buffer must fit in the LDS images");
+  hipLaunchKernelGGL(awq_gemm_kernel, dim3(col_tiles, row_tiles, ks), dim3(256), lds, static_cast<hipStream_t>(stream),
+                     static_cast<uint16_t*>(c), static_cast<const uint16_t*>(a), qweight,
+                     static_cast<const uint16_t*>(scales), qzeros, M, N, K, group_size, ks, partials, counters);
+  SW_CHECK_LAUNCH();
+  return SW_OK;
+}
+
+}  // extern "C"

@@ -61,7 +61,17 @@ _SIGNATURES = {
     "sw_kv_push": [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p],
     "sw_kv_signal": [_c_void_p, _c_int, ctypes.c_int32, _c_void_p],
     "sw_kv_wait": [_c_void_p, _c_int, ctypes.c_int32, _c_i64, _c_void_p, _c_void_p],
+    "sw_quant_gemm_workspace_bytes": [_c_int, _c_int, _c_int],
+    "sw_gptq_shuffle": [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p],
+    "sw_gptq_gemm": [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int,
+                     _c_int, _c_int, _c_int, _c_void_p, _c_i64, _c_void_p],
+    "sw_gptq_dequant": [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int,
+                        _c_int, _c_void_p],
+    "sw_awq_gemm": [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int,
+                    _c_void_p, _c_i64, _c_void_p],
+    "sw_awq_dequantize": [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p],
 }
+_RESTYPES = {"sw_quant_gemm_workspace_bytes": _c_i64}     # everything else returns an int status
 
 _lib = None
 
@@ -85,7 +95,7 @@ def load_library() -> ctypes.CDLL:
     for name, argtypes in _SIGNATURES.items():
         fn = getattr(lib, name)
         fn.argtypes = argtypes
-        fn.restype = _c_int
+        fn.restype = _RESTYPES.get(name, _c_int)
     _lib = lib
     return lib
 
@@ -411,6 +421,131 @@ def kv_wait(flags_ptr: int, slot: int, epoch: int, max_spins: int, status_ptr: i
     _check(load_library().sw_kv_wait(flags_ptr, slot, epoch, max_spins, status_ptr, stream))
 
 
+
+# ------------------------------------------------------------- int4 linear layers
+# Above this many rows a dense fp16 GEMM on the reconstructed weight beats streaming the int4
+# weight once per 64 rows; the reference switches at 50 rows (q_gemm.cu:1707, MAX_Q_GEMM_ROWS)
+# and, for AWQ, at 256 tokens (awq.py:161).
+GPTQ_FUSED_MAX_ROWS = 256
+_WORKSPACE_MIN_BYTES = 64 << 20
+_workspaces: Dict[tuple, List[torch.Tensor]] = {}
+
+
+def _quant_workspace(ref: torch.Tensor, m: int, n: int, k: int) -> torch.Tensor:
+    """Zero-initialised scratch for the fused GEMMs, one per (device, stream); replaced by a
+    larger one on demand (older ones stay alive: captured graphs may still name them)."""
+    want = min(int(load_library().sw_quant_gemm_workspace_bytes(m, n, k)), 1 << 30)
+    key = (ref.device.index, torch.cuda.current_stream(ref.device).cuda_stream)
+    pool = _workspaces.setdefault(key, [])
+    if not pool or pool[-1].numel() < want:
+        pool.append(torch.zeros(max(want, _WORKSPACE_MIN_BYTES), dtype=torch.uint8, device=ref.device))
+    return pool[-1]
+
+
+def _optional_index(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    """The reference passes a meta-device tensor where it means "no index" (gptq.py:206-214)."""
+    if t is None or t.device.type == "meta" or t.numel() == 0:
+        return None
+    if t.dtype != torch.int32:
+        raise RuntimeError("index tensors must be int32")
+    return t
+
+
+def _require_half(*tensors: torch.Tensor) -> None:
+    for t in tensors:
+        if t.dtype != torch.float16:
+            raise RuntimeError(f"int4 linear layers support float16 only, got {t.dtype}")
+
+
+def gptq_shuffle(q_weight: torch.Tensor, q_perm: Optional[torch.Tensor], bit: int) -> None:
+    """``ops.gptq_shuffle`` (csrc/quantization/gptq/q_gemm.cu:2748-2769): in place."""
+    _require_cuda(q_weight)
+    perm = _optional_index(q_perm)
+    scratch = torch.empty_like(q_weight) if perm is not None else None
+    k, n = q_weight.size(0) * 32 // bit, q_weight.size(1)
+    _check(load_library().sw_gptq_shuffle(q_weight.data_ptr(), perm.data_ptr() if perm is not None else None, k, n,
+                                          int(bit), scratch.data_ptr() if scratch is not None else None,
+                                          _stream(q_weight)))
+
+
+def gptq_dequant(b_q_weight: torch.Tensor, b_gptq_qzeros: torch.Tensor, b_gptq_scales: torch.Tensor,
+                 b_g_idx: Optional[torch.Tensor], bits: int, use_exllama: bool) -> torch.Tensor:
+    """``ops.dequant_gptq`` (q_gemm.cu:2820-2861): the fp16 weight [K, N]."""
+    _require_cuda(b_q_weight, b_gptq_qzeros, b_gptq_scales)
+    _require_half(b_gptq_scales)
+    idx = _optional_index(b_g_idx)
+    k, n = b_q_weight.size(0) * 32 // bits, b_q_weight.size(1)
+    out = torch.empty((k, n), dtype=torch.float16, device=b_q_weight.device)
+    _check(load_library().sw_gptq_dequant(out.data_ptr(), b_q_weight.data_ptr(), b_gptq_qzeros.data_ptr(),
+                                          b_gptq_scales.data_ptr(), idx.data_ptr() if idx is not None else None, k, n,
+                                          b_gptq_qzeros.size(0), int(bool(use_exllama)), int(bits),
+                                          _stream(b_q_weight)))
+    return out
+
+
+def gptq_gemm(a: torch.Tensor, b_q_weight: torch.Tensor, b_gptq_qzeros: torch.Tensor, b_gptq_scales: torch.Tensor,
+              b_g_idx: Optional[torch.Tensor], use_exllama: bool, bit: int) -> torch.Tensor:
+    """``ops.gptq_gemm`` (q_gemm.cu:2712-2746): a [M, K] fp16 -> [M, N] fp16."""
+    _require_cuda(a, b_q_weight, b_gptq_qzeros, b_gptq_scales)
+    _require_half(a, b_gptq_scales)
+    if not a.is_contiguous():
+        a = a.contiguous()
+    m, k = a.shape
+    n = b_q_weight.size(1)
+    if k != b_q_weight.size(0) * 32 // bit:
+        raise RuntimeError(f"gptq_gemm: input has {k} columns, weight has {b_q_weight.size(0) * 32 // bit} rows")
+    if m > GPTQ_FUSED_MAX_ROWS:
+        return torch.matmul(a, gptq_dequant(b_q_weight, b_gptq_qzeros, b_gptq_scales, b_g_idx, bit, use_exllama))
+    idx = _optional_index(b_g_idx)
+    c = torch.empty((m, n), dtype=torch.float16, device=a.device)
+    ws = _quant_workspace(a, m, n, k)
+    _check(load_library().sw_gptq_gemm(c.data_ptr(), a.data_ptr(), b_q_weight.data_ptr(), b_gptq_qzeros.data_ptr(),
+                                       b_gptq_scales.data_ptr(), idx.data_ptr() if idx is not None else None, m, n, k,
+                                       b_gptq_qzeros.size(0), int(bool(use_exllama)), int(bit), ws.data_ptr(),
+                                       ws.numel(), _stream(a)))
+    return c
+
+
+def awq_dequantize(qweight: torch.Tensor, scales: torch.Tensor, qzeros: torch.Tensor, split_k_iters: int = 0,
+                   thx: int = 0, thy: int = 0) -> torch.Tensor:
+    """``ops.awq_dequantize`` (csrc/quantization/awq/gemm_kernels.cu:585-640); the three launch
+    hints of the reference are accepted and ignored."""
+    del split_k_iters, thx, thy
+    _require_cuda(qweight, scales, qzeros)
+    _require_half(scales)
+    k, n = qweight.size(0), qweight.size(1) * 8
+    out = torch.empty((k, n), dtype=torch.float16, device=qweight.device)
+    _check(load_library().sw_awq_dequantize(out.data_ptr(), qweight.data_ptr(), scales.data_ptr(), qzeros.data_ptr(),
+                                            k, n, k // scales.size(0), _stream(qweight)))
+    return out
+
+
+def awq_gemm(x: torch.Tensor, qweight: torch.Tensor, scales: torch.Tensor, qzeros: torch.Tensor,
+             split_k_iters: int) -> torch.Tensor:
+    """``ops.awq_gemm`` (gemm_kernels.cu:648-705): x [M, K] fp16 -> [M, N] fp16.  ``split_k_iters``
+    sized the reference's partial-output tensor; the split is chosen natively here."""
+    del split_k_iters
+    _require_cuda(x, qweight, scales, qzeros)
+    _require_half(x, scales)
+    if not x.is_contiguous():
+        x = x.contiguous()
+    m, k = x.shape
+    n = qweight.size(1) * 8
+    group_size = k // scales.size(0)
+    # the reference throws std::invalid_argument for these (gemm_kernels.cu:671-678)
+    if n % 64 != 0:
+        raise ValueError("OC is not multiple of cta_N = 64")
+    if group_size % 32 != 0:
+        raise ValueError("Group size should be a multiple of 32")
+    if n % group_size != 0:
+        raise ValueError("OC is not multiple of Group size")
+    c = torch.empty((m, n), dtype=torch.float16, device=x.device)
+    ws = _quant_workspace(x, m, n, k)
+    _check(load_library().sw_awq_gemm(c.data_ptr(), x.data_ptr(), qweight.data_ptr(), scales.data_ptr(),
+                                      qzeros.data_ptr(), m, k, n, group_size, ws.data_ptr(), ws.numel(), _stream(x)))
+    return c
+
+
 # ------------------------------------------------------------------- cuda_utils
 def get_max_shared_memory_per_block_device_attribute(gpu: int) -> int:
     """``cuda_utils.get_max_shared_memory_per_block_device_attribute``
@@ -428,6 +563,11 @@ ops = SimpleNamespace(
     fused_add_rms_norm=fused_add_rms_norm,
     rotary_embedding=rotary_embedding,
     silu_and_mul=silu_and_mul,
+    gptq_shuffle=gptq_shuffle,
+    gptq_gemm=gptq_gemm,
+    dequant_gptq=gptq_dequant,
+    awq_gemm=awq_gemm,
+    awq_dequantize=awq_dequantize,
 )
 cache_ops = SimpleNamespace(
     reshape_and_cache=reshape_and_cache,
