@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Kernel micro-benchmarks with HIP-event timing: achieved algorithmic GB/s per kernel.
 
-  python tools/bench_kernels.py [paged|reshape|copy|all]
+  python tools/bench_kernels.py [paged|reshape|copy|quant|all]
 """
 import os
 import sys
@@ -91,6 +91,30 @@ def bench_copy(pairs, layers=32, kvh=32, d=128, bs=16, dtype=torch.bfloat16):
     print(f"copy_blocks pairs={pairs} layers={layers}: {t * 1e6:8.1f} us  {nbytes / t / 1e9:8.1f} GB/s")
 
 
+def bench_quant(m, k, n, fmt="gptq", group=128):
+    """One of the 13B / TP2 matrices: random int4 words, the stated group size."""
+    dev = "cuda"
+    a = torch.randn(m, k, dtype=torch.float16, device=dev)
+    scales = (torch.rand(k // group, n, device=dev) * 2e-3).to(torch.float16)
+    if fmt == "gptq":
+        qw = torch.randint(-2**31, 2**31 - 1, (k // 8, n), dtype=torch.int32, device=dev)
+        qz = torch.randint(-2**31, 2**31 - 1, (k // group, n // 8), dtype=torch.int32, device=dev)
+        fn = lambda: _C.ops.gptq_gemm(a, qw, qz, scales, None, True, 4)
+        dq = lambda: _C.ops.dequant_gptq(qw, qz, scales, None, 4, True)
+    else:
+        qw = torch.randint(-2**31, 2**31 - 1, (k, n // 8), dtype=torch.int32, device=dev)
+        qz = torch.randint(-2**31, 2**31 - 1, (k // group, n // 8), dtype=torch.int32, device=dev)
+        fn = lambda: _C.ops.awq_gemm(a, qw, scales, qz, 8)
+        dq = lambda: _C.ops.awq_dequantize(qw, scales, qz, 0, 0, 0)
+    t = timeit(fn, iters=50)
+    nbytes = k * n // 2 + (k // group) * n * 2 + (k // group) * n // 2 + m * k * 2 + m * n * 2
+    flops = 2.0 * m * n * k
+    w = dq()
+    t_dense = timeit(lambda: torch.matmul(a, w), iters=50)
+    print(f"{fmt}_gemm M={m} K={k} N={n} g={group}: {t * 1e6:8.1f} us  {nbytes / t / 1e9:8.1f} GB/s  "
+          f"{flops / t / 1e12:7.1f} TFLOP/s   (dense fp16 matmul on the reconstructed weight: {t_dense * 1e6:8.1f} us)")
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     if what in ("paged", "all"):
@@ -110,6 +134,18 @@ if __name__ == "__main__":
         bench_reshape(2048, 32)
         bench_reshape(49408, 32)
         bench_reshape(49408, 32, consecutive=False)
+    if what == "awq":
+        for m in (1, 8, 32, 128):
+            for (k, n) in [(5120, 13824), (6912, 5120)]:
+                bench_quant(m, k, n, fmt="awq")
+    if what in ("quant", "all"):
+        shapes = [(5120, 7680), (2560, 5120), (5120, 13824), (6912, 5120)]      # qkv, o, gate_up, down of 13B / TP2
+        for m in (1, 8, 32, 64, 128, 256):
+            for (k, n) in shapes:
+                bench_quant(m, k, n)
+        for m in (1, 8, 32, 128):
+            for (k, n) in shapes[2:]:
+                bench_quant(m, k, n, fmt="awq")
     if what in ("copy", "all"):
         bench_copy(8)
         bench_copy(64)

@@ -28,7 +28,9 @@
 //     arrive at a tile (counted with one atomic) adds the partials in a fixed order: one
 //     launch, no atomics on data, bitwise reproducible results.
 #include "common.cuh"
+#include <stdlib.h>
 #include <type_traits>
+#include <utility>
 
 namespace sw {
 namespace {
@@ -42,6 +44,29 @@ using lds_i16x4_ptr = __attribute__((address_space(3))) i16x4*;
 constexpr int kCounterInts = 4096;                  // head of the workspace: one arrival counter per tile
 constexpr int kCounterBytes = kCounterInts * 4;
 constexpr uint32_t kMagic = 0x64006400u;            // half2(1024, 1024)
+
+using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
+using u32x2 = __attribute__((ext_vector_type(2))) uint32_t;
+constexpr int kAuxSystem = 17;                      // sc0 | sc1: through every cache level, both ways
+
+// Partial tiles cross workgroups (and therefore XCDs, whose L2s do not snoop each other).  A
+// release/acquire fence pair would write back and invalidate a whole L2 per workgroup; instead
+// the partials themselves are stored and loaded through the caches, the stores are waited for,
+// and the arrival counter is a relaxed device-scope atomic.
+__device__ __forceinline__ int arrive(int32_t* counter) {
+  return __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>): loops whose index must be a
+// compile-time constant (register arrays)
+template <int... I, typename F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F&& f) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(std::make_integer_sequence<int, N>{}, f);
+}
 
 __device__ __forceinline__ h2 as_h2(uint32_t u) { return __builtin_bit_cast(h2, u); }
 __device__ __forceinline__ uint32_t as_u32(h2 v) { return __builtin_bit_cast(uint32_t, v); }
@@ -95,129 +120,31 @@ __device__ __forceinline__ uint32_t shuffle_nibbles(uint32_t qa) {
   return qb;
 }
 
-// ------------------------------------------------------------------ shared GEMM epilogue
-// acc[t][c][r] <-> row m0 + 32t + 8(r>>2) + 4*half + (r&3), column ncol + c.
-// Adds the four waves' accumulators through LDS (two passes of 8 accumulator rows), then either
-// stores fp16 or hands the fp32 tile to the cross-workgroup reduction.
-template <int MT, int NC>
-__device__ __forceinline__ void reduce_and_store(f32x16 (&acc)[MT][NC], float* red, uint16_t* c, int M, int N,
-                                                 int m0, int ncol0, int col_step, int ksplit, float* partials,
-                                                 int32_t* counters, int tile) {
-  // red: [wave 4][t MT][c NC][r8 8][lane 64]
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int half = lane >> 5;
-  __shared__ int s_last;
-  float sum[2][MT][NC][2];                            // [pass][t][c][which of this wave's two rows]
-#pragma unroll
-  for (int pass = 0; pass < 2; ++pass) {
-    __syncthreads();
-#pragma unroll
-    for (int t = 0; t < MT; ++t)
-#pragma unroll
-      for (int cc = 0; cc < NC; ++cc)
-#pragma unroll
-        for (int r8 = 0; r8 < 8; ++r8)
-          red[(((wave * MT + t) * NC + cc) * 8 + r8) * 64 + lane] = acc[t][cc][8 * pass + r8];
-    __syncthreads();
-#pragma unroll
-    for (int t = 0; t < MT; ++t)
-#pragma unroll
-      for (int cc = 0; cc < NC; ++cc)
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-          const int r8 = wave + 4 * e;
-          float v = 0.f;
-#pragma unroll
-          for (int w = 0; w < 4; ++w) v += red[(((w * MT + t) * NC + cc) * 8 + r8) * 64 + lane];
-          sum[pass][t][cc][e] = v;
-        }
-  }
-  // this thread now owns rows r = 8*pass + wave + 4e  ->  m = m0 + 32t + 16*pass + 8e + 4*half + wave
-  bool last = true;
-  if (ksplit > 1) {
-#pragma unroll
-    for (int pass = 0; pass < 2; ++pass)
-#pragma unroll
-      for (int t = 0; t < MT; ++t)
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-          const int m = m0 + 32 * t + 16 * pass + 8 * e + 4 * half + wave;
-          if (m >= M) continue;
-#pragma unroll
-          for (int g4 = 0; g4 < NC / 4; ++g4) {
-            const int n = ncol0 + g4 * col_step;
-            if (n >= N) continue;
-            float4 v = make_float4(sum[pass][t][4 * g4][e], sum[pass][t][4 * g4 + 1][e], sum[pass][t][4 * g4 + 2][e],
-                                   sum[pass][t][4 * g4 + 3][e]);
-            *reinterpret_cast<float4*>(partials + ((size_t)blockIdx.z * M + m) * N + n) = v;
-          }
-        }
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) s_last = (atomicAdd(&counters[tile], 1) == ksplit - 1);
-    __syncthreads();
-    last = s_last != 0;
-    if (last) __threadfence();
-  }
-  if (!last) return;
-#pragma unroll
-  for (int pass = 0; pass < 2; ++pass)
-#pragma unroll
-    for (int t = 0; t < MT; ++t)
-#pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        const int m = m0 + 32 * t + 16 * pass + 8 * e + 4 * half + wave;
-        if (m >= M) continue;
-#pragma unroll
-        for (int g4 = 0; g4 < NC / 4; ++g4) {
-          const int n = ncol0 + g4 * col_step;
-          if (n >= N) continue;
-          float4 v;
-          if (ksplit > 1) {
-            v = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int z = 0; z < ksplit; ++z) {          // fixed order: reproducible
-              const float4 p = *reinterpret_cast<const float4*>(partials + ((size_t)z * M + m) * N + n);
-              v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
-            }
-          } else {
-            v = make_float4(sum[pass][t][4 * g4][e], sum[pass][t][4 * g4 + 1][e], sum[pass][t][4 * g4 + 2][e],
-                            sum[pass][t][4 * g4 + 3][e]);
-          }
-          uint2 o;
-          o.x = (uint32_t)float_to_f16_bits(v.x) | ((uint32_t)float_to_f16_bits(v.y) << 16);
-          o.y = (uint32_t)float_to_f16_bits(v.z) | ((uint32_t)float_to_f16_bits(v.w) << 16);
-          *reinterpret_cast<uint2*>(c + (size_t)m * N + n) = o;
-        }
-      }
-  if (ksplit > 1 && threadIdx.x == 0) counters[tile] = 0;   // ready for the next call
-}
-
 // ------------------------------------------------------------------ GPTQ fused GEMM
-// grid (column tiles of 128, row tiles of 32*MT, k splits); 4 waves, each owning a contiguous
-// run of "units" of U k-steps (16 k each).  group_size must be a multiple of 16*U.
-template <int MT, int U>
-__global__ void __launch_bounds__(256)
-gptq_gemm_kernel(uint16_t* __restrict__ c, const uint16_t* __restrict__ a, const uint32_t* __restrict__ qweight,
-                 const uint32_t* __restrict__ qzeros, const uint16_t* __restrict__ scales, int M, int N, int K,
-                 int group_size, int ksplit, float* __restrict__ partials, int32_t* __restrict__ counters) {
-  extern __shared__ __attribute__((aligned(16))) float red[];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+// A wave streams a run of 16-k steps of one tile of 32*CP columns, keeping PF steps of loads in
+// flight in a register ring.
+//   lane (j = lane & 31, half = lane >> 5): columns n0 + CP*j .. +CP-1, k rows 8*half..+7 of a step
+//   acc[t][c][r] <-> row m0 + 32t + 8(r>>2) + 4*half + (r&3), column n0 + CP*j + c
+constexpr int kGemmWaves = 8;
+
+template <int CP> struct WordVec;
+template <> struct WordVec<2> { using type = uint2; using scale_t = uint32_t; };
+template <> struct WordVec<4> { using type = uint4; using scale_t = uint2; };
+
+template <int MT, int CP, int PF>
+__device__ __forceinline__ void gptq_stream(f32x16 (&acc)[MT][CP], const uint16_t* __restrict__ a,
+                                            const uint32_t* __restrict__ qweight, const uint32_t* __restrict__ qzeros,
+                                            const uint16_t* __restrict__ scales, int M, int N, int K, int group_size,
+                                            int m0, int ncl, int s_begin, int s_end) {
+  using wvec = typename WordVec<CP>::type;
+  using svec = typename WordVec<CP>::scale_t;
+  const int lane = threadIdx.x & 63;
   const int j = lane & 31, half = lane >> 5;
-  const int n0 = blockIdx.x * 128;
-  const int ncol = n0 + 4 * j;
-  const bool col_ok = ncol < N;
-  const int ncl = col_ok ? ncol : 0;                  // clamped column for loads
-  const int m0 = blockIdx.y * 32 * MT;
-
-  const int units = K / (16 * U);
-  const int nw = ksplit * 4, wg = blockIdx.z * 4 + wave;
-  const int u_begin = (int)((int64_t)units * wg / nw), u_end = (int)((int64_t)units * (wg + 1) / nw);
-
-  f32x16 acc[MT][4];
+  const int spg = group_size / 16;                    // steps per group
 #pragma unroll
   for (int t = 0; t < MT; ++t)
 #pragma unroll
-    for (int cc = 0; cc < 4; ++cc)
+    for (int cc = 0; cc < CP; ++cc)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[t][cc][r] = 0.f;
 
@@ -225,73 +152,334 @@ gptq_gemm_kernel(uint16_t* __restrict__ c, const uint16_t* __restrict__ a, const
 #pragma unroll
   for (int t = 0; t < MT; ++t) ap[t] = a + (size_t)min(m0 + 32 * t + j, M - 1) * K + 8 * half;
   const uint32_t* wp = qweight + (size_t)half * N + ncl;
-  const int zshift = 16 * (j & 1);                    // this lane's 4 zero nibbles inside the zeros word
+  const int zshift = 4 * (ncl & 7);                   // this lane's zero nibbles inside the zeros word
 
-  uint4 wq[2][U];
-  f16x8 af[2][U][MT];
-  uint32_t zq = 0;                                    // zeros word / scales of the NEXT group to set up
-  uint2 sq = make_uint2(0, 0);
-  GptqCol col[4];
-  int cur_group = -1;
+  // register ring; slot indices are compile-time so that nothing is spilled
+  wvec wq[PF];
+  f16x8 af[PF][MT];
+  uint32_t zq[PF];
+  svec sq[PF];
+  GptqCol col[CP];
+  int i_group = s_begin / spg;                        // group at the issue cursor
+  int i_boundary = (i_group + 1) * spg;               // first step of the next group, issue side
+  int c_boundary = i_boundary;                        // same, consume side
 
-  // BUF is a compile-time constant so that the double buffers stay in registers
-  auto load_unit = [&](auto BUF, int u) {
-    constexpr int buf = decltype(BUF)::value;
+  auto issue = [&](auto SLOT, int s) {
+    constexpr int slot = decltype(SLOT)::value;
+    if (s >= s_end) return;
+    wq[slot] = *reinterpret_cast<const wvec*>(wp + (size_t)(2 * s) * N);
 #pragma unroll
-    for (int s = 0; s < U; ++s) {
-      const int step = u * U + s;
-      wq[buf][s] = *reinterpret_cast<const uint4*>(wp + (size_t)(2 * step) * N);
-#pragma unroll
-      for (int t = 0; t < MT; ++t) af[buf][s][t] = *reinterpret_cast<const f16x8*>(ap[t] + 16 * step);
+    for (int t = 0; t < MT; ++t) af[slot][t] = *reinterpret_cast<const f16x8*>(ap[t] + 16 * s);
+    if (s == s_begin || s == i_boundary) {            // wave-uniform: the first step of a group carries its data
+      if (s == i_boundary) { ++i_group; i_boundary += spg; }
+      zq[slot] = qzeros[(size_t)i_group * (N / 8) + ncl / 8];
+      sq[slot] = *reinterpret_cast<const svec*>(scales + (size_t)i_group * N + ncl);
     }
   };
-  auto load_group = [&](int g) {
-    zq = qzeros[(size_t)g * (N / 8) + ncl / 8];
-    sq = *reinterpret_cast<const uint2*>(scales + (size_t)g * N + ncl);
-  };
-  auto run_unit = [&](auto BUF, int u) {
-    constexpr int buf = decltype(BUF)::value;
-    const int g = u * 16 * U / group_size;
-    if (g != cur_group) {                             // wave-uniform
-      const uint32_t z = zq >> zshift;
-      col[0] = gptq_col((z & 0xfu) + 1, (uint16_t)(sq.x & 0xffffu));
-      col[1] = gptq_col(((z >> 4) & 0xfu) + 1, (uint16_t)(sq.x >> 16));
-      col[2] = gptq_col(((z >> 8) & 0xfu) + 1, (uint16_t)(sq.y & 0xffffu));
-      col[3] = gptq_col(((z >> 12) & 0xfu) + 1, (uint16_t)(sq.y >> 16));
-      cur_group = g;
-    }
-    if (u + 1 < u_end) {                              // next unit's loads fly during this unit's math
-      load_unit(std::integral_constant<int, buf ^ 1>{}, u + 1);
-      const int gn = (u + 1) * 16 * U / group_size;
-      if (gn != g) load_group(gn);
-    }
-#pragma unroll
-    for (int s = 0; s < U; ++s) {
-      const uint4 w = wq[buf][s];
-      const f16x8 b0 = gptq_dequant8(w.x, col[0]);
-      const f16x8 b1 = gptq_dequant8(w.y, col[1]);
-      const f16x8 b2 = gptq_dequant8(w.z, col[2]);
-      const f16x8 b3 = gptq_dequant8(w.w, col[3]);
-#pragma unroll
-      for (int t = 0; t < MT; ++t) {
-        acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[buf][s][t], b0, acc[t][0], 0, 0, 0);
-        acc[t][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[buf][s][t], b1, acc[t][1], 0, 0, 0);
-        acc[t][2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[buf][s][t], b2, acc[t][2], 0, 0, 0);
-        acc[t][3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[buf][s][t], b3, acc[t][3], 0, 0, 0);
+  auto consume = [&](auto SLOT, int s) {
+    constexpr int slot = decltype(SLOT)::value;
+    if (s == s_begin || s == c_boundary) {
+      if (s == c_boundary) c_boundary += spg;
+      const uint32_t z = zq[slot] >> zshift;
+      if constexpr (CP == 4) {
+        col[0] = gptq_col((z & 0xfu) + 1, (uint16_t)(sq[slot].x & 0xffffu));
+        col[1] = gptq_col(((z >> 4) & 0xfu) + 1, (uint16_t)(sq[slot].x >> 16));
+        col[2] = gptq_col(((z >> 8) & 0xfu) + 1, (uint16_t)(sq[slot].y & 0xffffu));
+        col[3] = gptq_col(((z >> 12) & 0xfu) + 1, (uint16_t)(sq[slot].y >> 16));
+      } else {
+        col[0] = gptq_col((z & 0xfu) + 1, (uint16_t)(sq[slot] & 0xffffu));
+        col[1] = gptq_col(((z >> 4) & 0xfu) + 1, (uint16_t)(sq[slot] >> 16));
       }
     }
+    uint32_t w[CP];
+    if constexpr (CP == 4) { w[0] = wq[slot].x; w[1] = wq[slot].y; w[2] = wq[slot].z; w[3] = wq[slot].w; }
+    else { w[0] = wq[slot].x; w[1] = wq[slot].y; }
+#pragma unroll
+    for (int cc = 0; cc < CP; ++cc) {
+      const f16x8 b = gptq_dequant8(w[cc], col[cc]);
+#pragma unroll
+      for (int t = 0; t < MT; ++t)
+        acc[t][cc] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[slot][t], b, acc[t][cc], 0, 0, 0);
+    }
+  };
+  static_for<PF>([&](auto SLOT) { issue(SLOT, s_begin + decltype(SLOT)::value); });
+  for (int s = s_begin; s < s_end; s += PF) {
+    static_for<PF>([&](auto SLOT) {
+      constexpr int i = decltype(SLOT)::value;
+      if (s + i < s_end) {
+        consume(SLOT, s + i);
+        issue(SLOT, s + i + PF);
+      }
+    });
+  }
+}
+
+// Partial-tile exchange between the workgroups that split k: ROWS accumulator rows per thread.
+// `row_of(i)` gives the matrix row of the i-th value set, `val_of(i, c)` its CP column values.
+template <int CP, int ROWS, typename ValOf, typename RowOf>
+__device__ __forceinline__ void combine_and_store(ValOf val_of, RowOf row_of, bool col_ok, int ncol,
+                                                  uint16_t* __restrict__ c, int M, int N, int ksplit,
+                                                  float* __restrict__ partials, int32_t* __restrict__ counters,
+                                                  int tile, int* s_last) {
+  const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(partials, 0, (int)((size_t)ksplit * M * N * 4), 0x00020000);
+  bool last = true;
+  if (ksplit > 1) {
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) {
+      const int m = row_of(i);
+      if (m >= M || !col_ok) continue;
+      const int off = (int)((((size_t)blockIdx.z * M + m) * N + ncol) * 4);
+      if constexpr (CP == 4) {
+        const u32x4 v = {__float_as_uint(val_of(i, 0)), __float_as_uint(val_of(i, 1)), __float_as_uint(val_of(i, 2)),
+                         __float_as_uint(val_of(i, 3))};
+        __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, off, 0, kAuxSystem);
+      } else {
+        const u32x2 v = {__float_as_uint(val_of(i, 0)), __float_as_uint(val_of(i, 1))};
+        __builtin_amdgcn_raw_buffer_store_b64(v, rsrc, off, 0, kAuxSystem);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) *s_last = (arrive(&counters[tile]) == ksplit - 1);
+    __syncthreads();
+    last = *s_last != 0;
+  }
+  if (!last) return;
+  float v[ROWS][CP];
+#pragma unroll
+  for (int i = 0; i < ROWS; ++i)
+#pragma unroll
+    for (int cc = 0; cc < CP; ++cc) v[i][cc] = ksplit > 1 ? 0.f : val_of(i, cc);
+  if (ksplit > 1) {
+    for (int z = 0; z < ksplit; ++z) {                  // fixed order: reproducible
+      // all of this thread's loads of one split are issued before the first is used
+      float p[ROWS][CP];
+#pragma unroll
+      for (int i = 0; i < ROWS; ++i) {
+        const int m = row_of(i);
+        const bool ok = m < M && col_ok;
+        const int off = ok ? (int)((((size_t)z * M + m) * N + ncol) * 4) : 0;
+        if constexpr (CP == 4) {
+          const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, kAuxSystem);
+          p[i][0] = __uint_as_float(q.x); p[i][1] = __uint_as_float(q.y);
+          p[i][2] = __uint_as_float(q.z); p[i][3] = __uint_as_float(q.w);
+        } else {
+          const u32x2 q = __builtin_amdgcn_raw_buffer_load_b64(rsrc, off, 0, kAuxSystem);
+          p[i][0] = __uint_as_float(q.x); p[i][1] = __uint_as_float(q.y);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < ROWS; ++i)
+#pragma unroll
+        for (int cc = 0; cc < CP; ++cc) v[i][cc] += p[i][cc];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < ROWS; ++i) {
+    const int m = row_of(i);
+    if (m >= M || !col_ok) continue;
+    uint32_t o[CP / 2];
+#pragma unroll
+    for (int cc = 0; cc < CP; cc += 2)
+      o[cc / 2] = (uint32_t)float_to_f16_bits(v[i][cc]) | ((uint32_t)float_to_f16_bits(v[i][cc + 1]) << 16);
+    if constexpr (CP == 4) *reinterpret_cast<uint2*>(c + (size_t)m * N + ncol) = make_uint2(o[0], o[1]);
+    else *reinterpret_cast<uint32_t*>(c + (size_t)m * N + ncol) = o[0];
+  }
+  if (ksplit > 1 && threadIdx.x == 0)                    // ready for the next call
+    __hip_atomic_store(&counters[tile], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Variant "k across waves": grid (column tiles of 32*CP, row tiles, k splits); the 8 waves of a
+// workgroup split its k range and add up in LDS.
+template <int MT, int CP, int PF>
+__global__ void __launch_bounds__(kGemmWaves * 64)
+gptq_gemm_kwaves_kernel(uint16_t* __restrict__ c, const uint16_t* __restrict__ a, const uint32_t* __restrict__ qweight,
+                        const uint32_t* __restrict__ qzeros, const uint16_t* __restrict__ scales, int M, int N, int K,
+                        int group_size, int ksplit, float* __restrict__ partials, int32_t* __restrict__ counters) {
+  extern __shared__ __attribute__((aligned(16))) float red[];
+  __shared__ int s_last;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int half = lane >> 5;
+  const int ncol = blockIdx.x * 32 * CP + CP * (lane & 31);
+  const bool col_ok = ncol < N;
+  const int m0 = blockIdx.y * 32 * MT;
+  const int steps = K / 16;
+  const int nw = ksplit * kGemmWaves, wg = blockIdx.z * kGemmWaves + wave;
+  const int s_begin = (int)((int64_t)steps * wg / nw), s_end = (int)((int64_t)steps * (wg + 1) / nw);
+
+  f32x16 acc[MT][CP];
+  gptq_stream<MT, CP, PF>(acc, a, qweight, qzeros, scales, M, N, K, group_size, m0, col_ok ? ncol : 0, s_begin, s_end);
+
+  // two passes of 8 accumulator rows; wave w then owns accumulator row 8*pass + w
+  float vals[2 * MT][CP];
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+      for (int cc = 0; cc < CP; ++cc)
+#pragma unroll
+        for (int r8 = 0; r8 < 8; ++r8)
+          red[(((wave * MT + t) * CP + cc) * 8 + r8) * 64 + lane] = acc[t][cc][8 * pass + r8];
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+      for (int cc = 0; cc < CP; ++cc) {
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < kGemmWaves; ++w) v += red[(((w * MT + t) * CP + cc) * 8 + wave) * 64 + lane];
+        vals[pass * MT + t][cc] = v;
+      }
+  }
+  auto row_of = [&](int i) {                            // i = pass * MT + t, accumulator row r = 8*pass + wave
+    const int pass = i / MT, t = i % MT;
+    return m0 + 32 * t + 16 * pass + 8 * (wave >> 2) + 4 * half + (wave & 3);
+  };
+  auto val_of = [&](int i, int cc) { return vals[i][cc]; };
+  combine_and_store<CP, 2 * MT>(val_of, row_of, col_ok, ncol, c, M, N, ksplit, partials, counters,
+                                blockIdx.y * gridDim.x + blockIdx.x, &s_last);
+}
+
+// Variant "tiled" (more than 32 rows of A): grid (groups of 8 column tiles, row tiles of 32*MT,
+// k splits).  The 8 waves of a workgroup own 8 ADJACENT column tiles over the same k range, so
+// every weight word is unpacked exactly once per row tile and reused for all 32*MT rows, and
+// the A tile they all need goes through LDS in chunks of 256 k (double buffered, one barrier
+// per chunk, the next chunk's global loads in flight during this chunk's math).  k is split across workgroups only.
+constexpr int kChunkK = 256;                        // k per A chunk = 16 steps
+constexpr int kARow = kChunkK * 2 + 16;             // LDS bytes per A row; the pad keeps 16 rows on 64 distinct banks
+
+template <int MT, int CP>
+__global__ void __launch_bounds__(kGemmWaves * 64)
+gptq_gemm_tiled_kernel(uint16_t* __restrict__ c, const uint16_t* __restrict__ a, const uint32_t* __restrict__ qweight,
+                       const uint32_t* __restrict__ qzeros, const uint16_t* __restrict__ scales, int M, int N, int K,
+                       int group_size, int ksplit, float* __restrict__ partials, int32_t* __restrict__ counters) {
+  using wvec = typename WordVec<CP>::type;
+  using svec = typename WordVec<CP>::scale_t;
+  constexpr int PF = 8;                               // weight steps in flight
+  constexpr int SPC = kChunkK / 16;                   // steps per chunk
+  static_assert(SPC % PF == 0, "ring slots must line up with chunks");
+  constexpr int BM = 32 * MT;
+  constexpr int SEGS = kChunkK / 8;                   // 16-byte pieces per A row of a chunk
+  constexpr int PIECES = BM * SEGS;
+  constexpr int PPT = (PIECES + kGemmWaves * 64 - 1) / (kGemmWaves * 64);
+  extern __shared__ __attribute__((aligned(16))) char a_lds[];   // 2 x BM x kARow
+  __shared__ int s_last;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31, half = lane >> 5;
+  const int ncol = (blockIdx.x * kGemmWaves + wave) * 32 * CP + CP * j;
+  const bool col_ok = ncol < N;
+  const int ncl = col_ok ? ncol : 0;
+  const int m0 = blockIdx.y * BM;
+  const int chunks = K / kChunkK;
+  const int c_begin = (int)((int64_t)chunks * blockIdx.z / ksplit), c_end = (int)((int64_t)chunks * (blockIdx.z + 1) / ksplit);
+  const int s_begin = SPC * c_begin, s_end = SPC * c_end;
+  const int spg = group_size / 16;
+
+  f32x16 acc[MT][CP];
+#pragma unroll
+  for (int t = 0; t < MT; ++t)
+#pragma unroll
+    for (int cc = 0; cc < CP; ++cc)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][cc][r] = 0.f;
+
+  // ---- A staging: piece p = (row, 16-byte segment)
+  uint4 a_stage[PPT];
+  auto a_fetch = [&](int chunk) {
+#pragma unroll
+    for (int q = 0; q < PPT; ++q) {
+      const int p = tid + q * kGemmWaves * 64;
+      if (PIECES % (kGemmWaves * 64) != 0 && p >= PIECES) continue;
+      const int row = p / SEGS, seg = p % SEGS;
+      a_stage[q] = *reinterpret_cast<const uint4*>(a + (size_t)min(m0 + row, M - 1) * K + chunk * kChunkK + seg * 8);
+    }
+  };
+  auto a_commit = [&](int buf) {
+#pragma unroll
+    for (int q = 0; q < PPT; ++q) {
+      const int p = tid + q * kGemmWaves * 64;
+      if (PIECES % (kGemmWaves * 64) != 0 && p >= PIECES) continue;
+      const int row = p / SEGS, seg = p % SEGS;
+      *reinterpret_cast<uint4*>(a_lds + buf * BM * kARow + row * kARow + seg * 16) = a_stage[q];
+    }
   };
 
-  if (u_begin < u_end) {
-    load_unit(std::integral_constant<int, 0>{}, u_begin);
-    load_group(u_begin * 16 * U / group_size);
+  // ---- weight ring (as in gptq_stream)
+  const uint32_t* wp = qweight + (size_t)half * N + ncl;
+  const int zshift = 4 * (ncl & 7);
+  wvec wq[PF];
+  uint32_t zq[PF];
+  svec sq[PF];
+  GptqCol col[CP];
+  int i_group = s_begin / spg, i_boundary = (i_group + 1) * spg, c_boundary = i_boundary;
+  auto issue = [&](auto SLOT, int s) {
+    constexpr int slot = decltype(SLOT)::value;
+    if (s >= s_end) return;
+    wq[slot] = *reinterpret_cast<const wvec*>(wp + (size_t)(2 * s) * N);
+    if (s == s_begin || s == i_boundary) {
+      if (s == i_boundary) { ++i_group; i_boundary += spg; }
+      zq[slot] = qzeros[(size_t)i_group * (N / 8) + ncl / 8];
+      sq[slot] = *reinterpret_cast<const svec*>(scales + (size_t)i_group * N + ncl);
+    }
+  };
+  auto consume = [&](auto SLOT, int s, const char* a_buf, int step_in_chunk) {
+    constexpr int slot = decltype(SLOT)::value;
+    if (s == s_begin || s == c_boundary) {
+      if (s == c_boundary) c_boundary += spg;
+      const uint32_t z = zq[slot] >> zshift;
+      if constexpr (CP == 4) {
+        col[0] = gptq_col((z & 0xfu) + 1, (uint16_t)(sq[slot].x & 0xffffu));
+        col[1] = gptq_col(((z >> 4) & 0xfu) + 1, (uint16_t)(sq[slot].x >> 16));
+        col[2] = gptq_col(((z >> 8) & 0xfu) + 1, (uint16_t)(sq[slot].y & 0xffffu));
+        col[3] = gptq_col(((z >> 12) & 0xfu) + 1, (uint16_t)(sq[slot].y >> 16));
+      } else {
+        col[0] = gptq_col((z & 0xfu) + 1, (uint16_t)(sq[slot] & 0xffffu));
+        col[1] = gptq_col(((z >> 4) & 0xfu) + 1, (uint16_t)(sq[slot] >> 16));
+      }
+    }
+    f16x8 af[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+      af[t] = *reinterpret_cast<const f16x8*>(a_buf + (32 * t + j) * kARow + step_in_chunk * 32 + half * 16);
+    uint32_t w[CP];
+    if constexpr (CP == 4) { w[0] = wq[slot].x; w[1] = wq[slot].y; w[2] = wq[slot].z; w[3] = wq[slot].w; }
+    else { w[0] = wq[slot].x; w[1] = wq[slot].y; }
+#pragma unroll
+    for (int cc = 0; cc < CP; ++cc) {
+      const f16x8 b = gptq_dequant8(w[cc], col[cc]);
+#pragma unroll
+      for (int t = 0; t < MT; ++t) acc[t][cc] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[t], b, acc[t][cc], 0, 0, 0);
+    }
+  };
+
+  static_for<PF>([&](auto SLOT) { issue(SLOT, s_begin + decltype(SLOT)::value); });
+  if (c_begin < c_end) a_fetch(c_begin);
+  for (int chunk = c_begin; chunk < c_end; ++chunk) {
+    const int par = (chunk - c_begin) & 1;
+    a_commit(par);
+    __syncthreads();
+    if (chunk + 1 < c_end) a_fetch(chunk + 1);
+    const char* a_buf = a_lds + par * BM * kARow;
+    static_for<SPC>([&](auto STEP) {                    // SPC is a multiple of PF: ring slots are compile-time
+      constexpr int st = decltype(STEP)::value;
+      const int s = SPC * chunk + st;
+      consume(std::integral_constant<int, st % PF>{}, s, a_buf, st);
+      issue(std::integral_constant<int, st % PF>{}, s + PF);
+    });
   }
-  for (int u = u_begin; u < u_end; u += 2) {
-    run_unit(std::integral_constant<int, 0>{}, u);
-    if (u + 1 < u_end) run_unit(std::integral_constant<int, 1>{}, u + 1);
-  }
-  reduce_and_store<MT, 4>(acc, red, c, M, N, m0, ncol, 0, ksplit, partials, counters,
-                          blockIdx.y * gridDim.x + blockIdx.x);
+
+  auto row_of = [&](int i) {
+    const int t = i / 16, r = i % 16;
+    return m0 + 32 * t + 8 * (r >> 2) + 4 * half + (r & 3);
+  };
+  auto val_of = [&](int i, int cc) { return acc[i / 16][cc][i % 16]; };
+  combine_and_store<CP, 16 * MT>(val_of, row_of, col_ok, ncol, c, M, N, ksplit, partials, counters,
+                                 blockIdx.y * gridDim.x + blockIdx.x, &s_last);
 }
 
 // ------------------------------------------------------------------ GPTQ, plain (unshuffled) weights + g_idx
@@ -567,6 +755,7 @@ awq_gemm_kernel(uint16_t* __restrict__ c, const uint16_t* __restrict__ a, const 
   }
   // this thread owns row m0 + 8*pass + 4*half + wave, columns n0 + 32*cb + j
   bool last = true;
+  const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(partials, 0, (int)((size_t)ksplit * M * N * 4), 0x00020000);
   if (ksplit > 1) {
 #pragma unroll
     for (int pass = 0; pass < 4; ++pass) {
@@ -575,17 +764,41 @@ awq_gemm_kernel(uint16_t* __restrict__ c, const uint16_t* __restrict__ a, const 
 #pragma unroll
       for (int cb = 0; cb < 8; ++cb) {
         const int n = n0 + 32 * cb + j;
-        if (n < N) partials[((size_t)blockIdx.z * M + m) * N + n] = sum[pass][cb];
+        if (n < N)
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(sum[pass][cb]), rsrc,
+                                                (int)((((size_t)blockIdx.z * M + m) * N + n) * 4), 0, kAuxSystem);
       }
     }
-    __threadfence();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x == 0) s_last = (atomicAdd(&counters[tile], 1) == ksplit - 1);
+    if (threadIdx.x == 0) s_last = (arrive(&counters[tile]) == ksplit - 1);
     __syncthreads();
     last = s_last != 0;
-    if (last) __threadfence();
   }
   if (!last) return;
+  if (ksplit > 1) {
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass)
+#pragma unroll
+      for (int cb = 0; cb < 8; ++cb) sum[pass][cb] = 0.f;
+    for (int z = 0; z < ksplit; ++z) {                  // fixed order; one batch of loads per split
+      float p[4][8];
+#pragma unroll
+      for (int pass = 0; pass < 4; ++pass) {
+        const int m = m0 + 8 * pass + 4 * half + wave;
+#pragma unroll
+        for (int cb = 0; cb < 8; ++cb) {
+          const int n = n0 + 32 * cb + j;
+          const int off = (m < M && n < N) ? (int)((((size_t)z * M + m) * N + n) * 4) : 0;
+          p[pass][cb] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, off, 0, kAuxSystem));
+        }
+      }
+#pragma unroll
+      for (int pass = 0; pass < 4; ++pass)
+#pragma unroll
+        for (int cb = 0; cb < 8; ++cb) sum[pass][cb] += p[pass][cb];
+    }
+  }
 #pragma unroll
   for (int pass = 0; pass < 4; ++pass) {
     const int m = m0 + 8 * pass + 4 * half + wave;
@@ -593,29 +806,31 @@ awq_gemm_kernel(uint16_t* __restrict__ c, const uint16_t* __restrict__ a, const 
 #pragma unroll
     for (int cb = 0; cb < 8; ++cb) {
       const int n = n0 + 32 * cb + j;
-      if (n >= N) continue;
-      float v = sum[pass][cb];
-      if (ksplit > 1) {
-        v = 0.f;
-        for (int z = 0; z < ksplit; ++z) v += partials[((size_t)z * M + m) * N + n];
-      }
-      c[(size_t)m * N + n] = float_to_f16_bits(v);
+      if (n < N) c[(size_t)m * N + n] = float_to_f16_bits(sum[pass][cb]);
     }
   }
-  if (ksplit > 1 && threadIdx.x == 0) counters[tile] = 0;
+  if (ksplit > 1 && threadIdx.x == 0)
+    __hip_atomic_store(&counters[tile], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // how many ways to split k across workgroups: aim at two workgroups per compute unit, keep at
 // least `min_units` units of work per wave, and stay inside the workspace
-int pick_ksplit(int tiles, int units, int min_units, int M, int N, int64_t workspace_bytes) {
+int pick_ksplit(int tiles, int units, int min_units, int M, int N, int64_t workspace_bytes, int waves = 4,
+                int target_wgs = 512) {
   if (tiles > kCounterInts) return 1;
-  int ks = (512 + tiles - 1) / tiles;
-  const int cap = units / (4 * min_units);
+  int ks = (target_wgs + tiles / 2) / tiles;
+  const int cap = units / (waves * min_units);
   if (ks > cap) ks = cap;
   if (ks > 64) ks = 64;
+  if (const char* env = getenv("SW_QUANT_KSPLIT")) {          // experiments only; clamped like any other choice
+    const int forced = atoi(env);
+    if (forced >= 1 && forced * waves <= units) ks = forced;
+  }
   const int64_t per_split = (int64_t)M * N * 4;
   const int64_t room = (workspace_bytes - kCounterBytes) / (per_split > 0 ? per_split : 1);
   if (ks > room) ks = (int)room;
+  const int64_t addressable = ((int64_t)1 << 31) / (per_split > 0 ? per_split : 1);   // 32-bit buffer offsets
+  if (ks > addressable) ks = (int)addressable;
   return ks < 1 ? 1 : ks;
 }
 
@@ -676,12 +891,12 @@ int sw_gptq_gemm(void* c, const void* a, const uint32_t* qweight, const uint32_t
                "gptq_gemm: bad shape M=%d N=%d K=%d groups=%d", M, N, K, groups);
   if (M == 0) return SW_OK;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  uint16_t* cp = static_cast<uint16_t*>(c);
+  uint16_t* out = static_cast<uint16_t*>(c);
   const uint16_t* ap = static_cast<const uint16_t*>(a);
   const uint16_t* sp = static_cast<const uint16_t*>(scales);
   if (!use_exllama) {
     SW_CHECK_ARG(g_idx != nullptr, "gptq_gemm: plain (unshuffled) weights need g_idx");
-    hipLaunchKernelGGL(gptq_alt_gemm_kernel, dim3((N + 63) / 64, (M + 7) / 8), dim3(256), 0, st, cp, ap, qweight,
+    hipLaunchKernelGGL(gptq_alt_gemm_kernel, dim3((N + 63) / 64, (M + 7) / 8), dim3(256), 0, st, out, ap, qweight,
                        qzeros, sp, g_idx, M, N, K);
     SW_CHECK_LAUNCH();
     return SW_OK;
@@ -705,21 +920,40 @@ int sw_gptq_gemm(void* c, const void* a, const uint32_t* qweight, const uint32_t
     ap = a_perm;
   }
   float* partials = reinterpret_cast<float*>(ws + kCounterBytes);
-  const bool wide = (group_size % 64 == 0) && (K % 64 == 0);
-  const int mt = M > 32 ? 2 : 1;
-  const int u = !wide ? 1 : (mt == 1 ? 4 : 2);
-  const int col_tiles = (N + 127) / 128, row_tiles = (M + 32 * mt - 1) / (32 * mt);
-  const int ks = pick_ksplit(col_tiles * row_tiles, K / (16 * u), 2, M, N, avail);
-  const dim3 grid(col_tiles, row_tiles, ks);
-  const size_t lds = (size_t)4 * mt * 4 * 8 * 64 * 4;
-#define SW_GPTQ_LAUNCH(MT_, U_)                                                                             \
-  hipLaunchKernelGGL((gptq_gemm_kernel<MT_, U_>), grid, dim3(256), lds, st, cp, ap, qweight, qzeros, sp, M, N, K, \
-                     group_size, ks, partials, counters)
-  if (mt == 1 && u == 4) SW_GPTQ_LAUNCH(1, 4);
-  else if (mt == 2 && u == 2) SW_GPTQ_LAUNCH(2, 2);
-  else if (mt == 1) SW_GPTQ_LAUNCH(1, 1);
-  else SW_GPTQ_LAUNCH(2, 1);
-#undef SW_GPTQ_LAUNCH
+  int cp = 2, mt = M > 32 ? 2 : 1;
+  bool tiled = M > 64 && K % kChunkK == 0;
+  if (const char* env = getenv("SW_QUANT_CP")) cp = atoi(env) == 4 ? 4 : 2;          // experiments only
+  if (const char* env = getenv("SW_QUANT_MT")) mt = atoi(env);
+  if (const char* env = getenv("SW_QUANT_TILED")) tiled = atoi(env) != 0 && K % kChunkK == 0;
+  if (mt > 2) mt = 2;
+  const int row_tiles = (M + 32 * mt - 1) / (32 * mt);
+  if (tiled) {
+    const int tile_cols = 32 * cp * kGemmWaves;
+    const int col_tiles = (N + tile_cols - 1) / tile_cols;
+    const int ks = pick_ksplit(col_tiles * row_tiles, K / kChunkK, 2, M, N, avail, 1, 256);
+    const dim3 grid(col_tiles, row_tiles, ks);
+    const size_t lds = (size_t)2 * 32 * mt * kARow;
+#define SW_GPTQ_TILED(MT_, CP_)                                                                                 \
+  hipLaunchKernelGGL((gptq_gemm_tiled_kernel<MT_, CP_>), grid, dim3(kGemmWaves * 64), lds, st, out, ap, qweight, \
+                     qzeros, sp, M, N, K, group_size, ks, partials, counters)
+    if (mt == 1 && cp == 2) SW_GPTQ_TILED(1, 2);
+    else if (mt == 1) SW_GPTQ_TILED(1, 4);
+    else if (mt == 2 && cp == 2) SW_GPTQ_TILED(2, 2);
+    else SW_GPTQ_TILED(2, 4);
+#undef SW_GPTQ_TILED
+  } else {
+    const int col_tiles = (N + 32 * cp - 1) / (32 * cp);
+    const int ks = pick_ksplit(col_tiles * row_tiles, K / 16, 8, M, N, avail, kGemmWaves, 256);
+    const dim3 grid(col_tiles, row_tiles, ks);
+    const size_t lds = (size_t)kGemmWaves * mt * cp * 8 * 64 * 4;
+#define SW_GPTQ_KWAVES(MT_, CP_)                                                                                     \
+  hipLaunchKernelGGL((gptq_gemm_kwaves_kernel<MT_, CP_, 8>), grid, dim3(kGemmWaves * 64), lds, st, out, ap, qweight, \
+                     qzeros, sp, M, N, K, group_size, ks, partials, counters)
+    if (mt == 1 && cp == 2) SW_GPTQ_KWAVES(1, 2);
+    else if (mt == 1) SW_GPTQ_KWAVES(1, 4);
+    else SW_GPTQ_KWAVES(2, 2);
+#undef SW_GPTQ_KWAVES
+  }
   SW_CHECK_LAUNCH();
   return SW_OK;
 }
@@ -749,7 +983,7 @@ int sw_awq_gemm(void* c, const void* a, const uint32_t* qweight, const void* sca
   int32_t* counters = static_cast<int32_t*>(workspace);
   float* partials = reinterpret_cast<float*>(static_cast<char*>(workspace) + kCounterBytes);
   const int col_tiles = (N + 255) / 256, row_tiles = (M + 31) / 32;
-  const int ks = pick_ksplit(col_tiles * row_tiles, K / 16, 4, M, N, workspace_bytes);
+  const int ks = pick_ksplit(col_tiles * row_tiles, K / 16, 8, M, N, workspace_bytes, 4, 384);
   const size_t lds = (size_t)4 * kAwqImage;           // four wave images; the reduction buffer reuses them
   static_assert(4 * 8 * 4 * 64 * 4 <= 4 * kAwqImage, "the reduction buffer must fit in the LDS images");
   hipLaunchKernelGGL(awq_gemm_kernel, dim3(col_tiles, row_tiles, ks), dim3(256), lds, static_cast<hipStream_t>(stream),
