@@ -12,9 +12,29 @@ from oracle import model as omodel
 pytestmark = pytest.mark.gpu
 
 
+def _dense_state_dict(sd, quantization):
+    """Replaces every int4 linear layer by the fp16 weight the CPU restatement reconstructs from
+    it (GPTQ weights have been shuffled in place by the first forward pass)."""
+    from oracle import quant
+    out = dict(sd)
+    for key in sd:
+        if not key.endswith(".qweight"):
+            continue
+        prefix = key[:-len("qweight")]
+        qw, qz, sc = (sd[prefix + n].numpy() for n in ("qweight", "qzeros", "scales"))
+        if quantization == "gptq":
+            w = quant.gptq_dequant(qw, qz, sc, None, use_exllama=True)
+        else:
+            w = quant.awq_dequantize(qw, sc, qz)
+        out[prefix + "weight"] = torch.from_numpy(w.T.copy())          # [out, in] like a dense layer
+    return out
+
+
 def _check_greedy(llm, prompts, outputs, tol):
     runner = llm.llm_engine.model_executor.driver_worker.model_runner
     sd = {k: v.detach().cpu() for k, v in runner.model.state_dict().items()}
+    if runner.model_config.quantization is not None:
+        sd = _dense_state_dict(sd, runner.model_config.quantization)
     cfg = runner.model_config.hf_config
     for prompt, out in zip(prompts, outputs):
         gen = out.outputs[0].token_ids
@@ -35,6 +55,22 @@ def test_greedy_generation_matches_cpu_model(model, enforce_eager):
     outs = llm.generate(prompt_token_ids=prompts, sampling_params=SamplingParams(temperature=0.0, max_tokens=24))
     assert [o.request_id for o in outs] == [str(i) for i in range(len(prompts))]
     assert all(len(o.outputs[0].token_ids) == 24 and o.outputs[0].finish_reason == "length" for o in outs)
+    _check_greedy(llm, prompts, outs, tol=3e-2)
+    del llm
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("quantization", ["gptq", "awq"])
+def test_int4_models_match_cpu_model(quantization):
+    """Llama geometry with every linear layer in int4 (random words, group size 128): the engine's
+    dequant-GEMM path against the CPU model run on the reconstructed fp16 weights."""
+    from splitwise_amd import LLM, SamplingParams
+    random.seed(2)
+    llm = LLM("llama-tiny", quantization=quantization, enforce_eager=True, num_gpu_blocks_override=128,
+              max_num_seqs=8, max_model_len=512, swap_space=0.01)
+    vocab = llm.llm_engine.model_config.get_vocab_size()
+    prompts = [[random.randrange(vocab) for _ in range(n)] for n in (5, 33, 64, 17, 300, 1)]
+    outs = llm.generate(prompt_token_ids=prompts, sampling_params=SamplingParams(temperature=0.0, max_tokens=12))
     _check_greedy(llm, prompts, outs, tol=3e-2)
     del llm
     torch.cuda.empty_cache()

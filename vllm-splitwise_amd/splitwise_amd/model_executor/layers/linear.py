@@ -15,6 +15,16 @@ import torch.nn.functional as F
 from ..parallel_state import get_tensor_model_parallel_world_size, tensor_model_parallel_all_reduce
 
 
+def set_weight_attrs(weight: torch.Tensor, attrs: Optional[Dict[str, Any]]) -> None:
+    """Metadata a checkpoint loader reads to shard a parameter (input_dim / output_dim /
+    packed_dim / pack_factor), as vllm/model_executor/utils.py:20-35."""
+    if attrs is None:
+        return
+    for key, value in attrs.items():
+        assert not hasattr(weight, key), f"Overwriting existing tensor attribute: {key}"
+        setattr(weight, key, value)
+
+
 class LinearMethodBase:
     def create_weights(self, input_size_per_partition: int, output_size_per_partition: int, input_size: int,
                        output_size: int, params_dtype: torch.dtype) -> Dict[str, Any]:
@@ -53,12 +63,9 @@ class _LinearBase(nn.Module):
         self.bias = nn.Parameter(torch.zeros(out_per_part, dtype=params_dtype), requires_grad=False) if bias else None
 
     def _weights(self) -> Dict[str, Any]:
-        # parameters may have been moved (.to(device)): always hand the live tensors to the method
-        live = dict(self.linear_weights)
-        for name in live:
-            if name in self._parameters:
-                live[name] = self._parameters[name]
-        return live
+        # the dict itself: a method may keep per-layer state in it (GPTQ's shuffle flag).  Module.to()
+        # moves parameters in place, so the Parameter objects named here stay the live ones.
+        return self.linear_weights
 
 
 class ColumnParallelLinear(_LinearBase):

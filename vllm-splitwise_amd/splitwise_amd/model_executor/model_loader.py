@@ -22,7 +22,12 @@ def _linear_method(model_config: ModelConfig):
     if model_config.quantization is None:
         return None
     from .layers.quantization import get_linear_method
-    return get_linear_method(model_config.quantization, model_config.hf_config)
+    method = get_linear_method(model_config.quantization, model_config.hf_config)
+    supported = method.quant_config.get_supported_act_dtypes()
+    if model_config.dtype not in supported:              # vllm/model_executor/model_loader.py:57-62
+        raise ValueError(f"{model_config.dtype} is not supported for quantization method "
+                         f"{model_config.quantization}. Supported dtypes: {supported}")
+    return method
 
 
 @torch.no_grad()
@@ -33,6 +38,8 @@ def _random_init(model: nn.Module, seed: int) -> None:
         if dev not in gen:
             gen[dev] = torch.Generator(device=dev).manual_seed(seed)
         g = gen[dev]
+        if name.endswith("g_idx"):
+            continue                                  # keeps its sequential group index
         if not p.is_floating_point():
             # packed int4 words: uniformly random bits
             p.copy_(torch.randint(-2 ** 31, 2 ** 31 - 1, p.shape, dtype=torch.int64, device=dev,
