@@ -1,0 +1,146 @@
+"""CPU stand-ins for the two workers of a split pair, used to drive the REAL control plane
+(engine -> SplitwiseExecutor -> channel -> worker_loop) across two processes without a GPU.
+
+The "KV cache" of a worker is a file-backed int64 array [num_blocks, block_size] holding token
+ids, plus an epoch flag per hand-off slot; the prompt side maps the token side's file (the
+stand-in for the IPC mapping) and copies block runs into it.  The token side computes every new
+token FROM ITS CACHE, so a missing or late block push, a wrong block table, run or epoch shows
+up as a wrong token or a failed wait.
+"""
+import os
+import time
+from typing import Dict, List, Optional
+
+import numpy as np
+
+from splitwise_amd.sequence import Logprob, SamplerOutput, SequenceGroupOutput, SequenceOutput
+
+VOCAB = 512
+
+
+def next_token(tokens: List[int]) -> int:
+    acc = 0
+    for i, t in enumerate(tokens):
+        acc = (acc * 31 + t + i) % 1000003
+    return acc % VOCAB
+
+
+class _FakeComm:
+    def __init__(self) -> None:
+        self.bytes_pushed = 0
+
+
+class _FakeCommManager:
+    def __init__(self) -> None:
+        self.kvcache_comm = _FakeComm()
+
+    def check_status(self) -> None:
+        pass
+
+
+class _FakeRunner:
+    enforce_eager = True
+
+
+class FakeWorker:
+    def __init__(self, model_config, parallel_config, scheduler_config, device_config, local_rank, rank,
+                 kv_cache_dtype, is_driver_worker, kv_transport_init) -> None:
+        self.rank = rank
+        self.is_prompt = rank == 0
+        self.exchange = kv_transport_init["exchange"]
+        self.dir = os.environ["SPLIT_FAKE_DIR"]
+        self.model_runner = _FakeRunner()
+        self.kvcache_comm_manager = _FakeCommManager()
+        self.cache = self.flags = self.peer_cache = self.peer_flags = None
+        self.block_size = 16
+        self.log: List[str] = []
+
+    # ---- life cycle, as Worker
+    def init_model(self) -> None:
+        pass
+
+    def load_model(self) -> None:
+        pass
+
+    def profile_num_available_blocks(self, block_size, gpu_memory_utilization, cpu_swap_space, cache_dtype):
+        small = int(os.environ.get("SPLIT_FAKE_BLOCKS", "64"))
+        return (small if self.is_prompt else small + 16), 8  # the executor must take the smaller one
+
+    def get_cache_block_size_bytes(self, block_size, cache_dtype) -> int:
+        return block_size * 8
+
+    def init_cache_engine(self, cache_config) -> None:
+        self.block_size = cache_config.block_size
+        n = cache_config.num_gpu_blocks
+        self.cache = np.lib.format.open_memmap(os.path.join(self.dir, f"cache{self.rank}.npy"), mode="w+",
+                                               dtype=np.int64, shape=(n, self.block_size))
+        self.cache[:] = -1
+        self.flags = np.lib.format.open_memmap(os.path.join(self.dir, f"flags{self.rank}.npy"), mode="w+",
+                                               dtype=np.int64, shape=(256,))
+        self.flags[:] = 0
+
+    def warm_up_model(self) -> None:
+        pass
+
+    def setup_kvcache_comm(self) -> None:
+        peer = self.exchange({"rank": self.rank, "blocks": int(self.cache.shape[0])})
+        assert peer["rank"] == 1 - self.rank and peer["blocks"] == self.cache.shape[0], peer
+        if self.is_prompt:
+            self.peer_cache = np.load(os.path.join(self.dir, "cache1.npy"), mmap_mode="r+")
+            self.peer_flags = np.load(os.path.join(self.dir, "flags1.npy"), mmap_mode="r+")
+        self.exchange({"rank": self.rank, "ready": True})
+
+    def destroy_kvcache_comm(self) -> None:
+        pass
+
+    # ---- one step
+    def _write(self, block_table: List[int], pos: int, token: int) -> None:
+        self.cache[block_table[pos // self.block_size], pos % self.block_size] = token
+
+    def _read(self, block_table: List[int], n: int) -> List[int]:
+        return [int(self.cache[block_table[i // self.block_size], i % self.block_size]) for i in range(n)]
+
+    def execute_model(self, seq_group_metadata_list=None, blocks_to_swap_in=None, blocks_to_swap_out=None,
+                      blocks_to_copy=None, blocks_to_nw=None, nw_epochs=None) -> SamplerOutput:
+        blocks_to_nw = blocks_to_nw or {}
+        outputs = []
+        if self.is_prompt:
+            for meta in seq_group_metadata_list:
+                assert meta.is_prompt
+                (seq_id, data), = meta.seq_data.items()
+                tokens = data.get_token_ids()
+                table = meta.block_tables[seq_id]
+                for pos, tok in enumerate(tokens):
+                    self._write(table, pos, tok)
+                tok = next_token(tokens)
+                outputs.append(SequenceGroupOutput([SequenceOutput(seq_id, tok, {tok: Logprob(0.0)})]))
+            time.sleep(0.002)                              # the decode step on the other side overlaps this one
+            for slot, runs in blocks_to_nw.items():
+                for start, count in runs:
+                    self.peer_cache[start:start + count] = self.cache[start:start + count]
+                    self.kvcache_comm_manager.kvcache_comm.bytes_pushed += count * self.block_size * 8
+                self.peer_cache.flush()
+                self.peer_flags[slot] = nw_epochs[slot]    # signal after the data
+                self.peer_flags.flush()
+            return SamplerOutput(outputs)
+        # token side: wait for every hand-off this step depends on, then decode from the cache
+        for slot in blocks_to_nw:
+            deadline = time.monotonic() + 20.0
+            while int(self.flags[slot]) < nw_epochs[slot]:
+                if time.monotonic() > deadline:
+                    raise RuntimeError(f"hand-off wait timed out on slot {slot} (epoch {nw_epochs[slot]})")
+                time.sleep(0.0005)
+        for meta in seq_group_metadata_list:
+            assert not meta.is_prompt
+            (seq_id, data), = meta.seq_data.items()
+            tokens = data.get_token_ids()
+            table = meta.block_tables[seq_id]
+            self._write(table, len(tokens) - 1, tokens[-1])          # this step's own KV entry
+            cached = self._read(table, len(tokens))
+            if cached != tokens:
+                bad = next(i for i, (a, b) in enumerate(zip(cached, tokens)) if a != b)
+                raise RuntimeError(f"request {meta.request_id}: cache differs from the sequence at position {bad} "
+                                   f"(block {table[bad // self.block_size]})")
+            tok = next_token(cached)
+            outputs.append(SequenceGroupOutput([SequenceOutput(seq_id, tok, {tok: Logprob(0.0)})]))
+        return SamplerOutput(outputs)

@@ -1,0 +1,97 @@
+"""The N>1 host path on CPU, world_size 2 over gloo: the engine with the split executor on rank 0
+and the token worker's command loop on rank 1, both with CPU stand-in workers (tests/split_fakes.py).
+Everything else is the product code: scheduler split scheduling and hand-off epochs, the executor's
+overlapped dispatch, the object channel, the worker loop and the transport handshake."""
+import os
+import random
+import socket
+import tempfile
+
+import pytest
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _rank_main(rank: int, port: int, tmpdir: str, result_path: str, blocks: int) -> None:
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, here)
+    import conftest  # noqa: F401  (adds the package and the repo root to sys.path)
+    os.environ["SPLIT_FAKE_DIR"] = tmpdir
+    os.environ["SPLIT_FAKE_BLOCKS"] = str(blocks)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=2)
+    from split_fakes import VOCAB, FakeWorker, next_token
+    from splitwise_amd import EngineArgs, LLMEngine, SamplingParams
+    from splitwise_amd.executor.channel import DistChannel
+    from splitwise_amd.executor.remote_worker import worker_loop
+    from splitwise_amd.executor.splitwise_executor import SplitwiseExecutor
+
+    args = EngineArgs(model="llama-tiny", sep_prompt_token=True, max_num_seqs=6, max_model_len=128,
+                      max_num_batched_tokens=512, swap_space=0.001)
+    mc, cc, pc, sc, dc = args.create_engine_configs()
+    if rank == 1:
+        cfg = {"model_config": mc, "parallel_config": pc, "scheduler_config": sc, "cache_config": cc, "rank": 1,
+               "local_rank": 0, "transport": "kernel"}
+        worker_loop(DistChannel(0), cfg, worker_cls=FakeWorker)
+        dist.barrier()
+        return
+    executor = SplitwiseExecutor(mc, cc, pc, sc, dc, channel=DistChannel(1), worker_cls=FakeWorker)
+    assert cc.num_gpu_blocks == blocks                           # the smaller of the two pools
+    engine = LLMEngine(mc, cc, pc, sc, dc, executor=executor)
+    rng = random.Random(0)
+    prompts = {str(i): [rng.randrange(VOCAB) for _ in range(rng.choice([1, 5, 16, 17, 40, 60]))] for i in range(14)}
+    lens = {rid: rng.choice([1, 2, 9, 30, 40]) for rid in prompts}
+    pending = list(prompts)
+    finished = {}
+    steps = 0
+    while pending or engine.has_unfinished_requests():
+        if pending and steps % 2 == 0:                           # requests keep arriving while others decode
+            rid = pending.pop(0)
+            engine.add_request(rid, None, SamplingParams(temperature=0.0, max_tokens=lens[rid], ignore_eos=True),
+                               prompt_token_ids=prompts[rid])
+        for out in engine.step():
+            if out.finished:
+                finished[out.request_id] = list(out.outputs[0].token_ids)
+        steps += 1
+        assert steps < 2000
+    expected = {}
+    for rid, prompt in prompts.items():
+        seq = list(prompt)
+        for _ in range(lens[rid]):
+            seq.append(next_token(seq))
+        expected[rid] = seq[len(prompt):]
+    pushed = executor.kv_bytes_pushed()
+    preempted = getattr(engine.scheduler, "num_preemptions", 0)
+    executor.shutdown()
+    verdict = "ok" if finished == expected and pushed > 0 else f"mismatch: {finished} != {expected} pushed={pushed}"
+    if blocks < 64 and preempted == 0:
+        verdict = "the small cache did not force a single preemption: the scenario tests nothing"
+    with open(result_path, "w") as f:
+        f.write(verdict)
+    dist.barrier()
+
+
+@pytest.mark.parametrize("blocks", [64, 16])       # 16 blocks: decodes run out of cache, sequences are
+def test_split_engine_over_gloo_world_size_2(blocks):  # preempted, recomputed and handed over again
+    with tempfile.TemporaryDirectory() as tmp:
+        result = os.path.join(tmp, "result.txt")
+        mp.spawn(_rank_main, args=(_free_port(), tmp, result, blocks), nprocs=2, join=True)
+        assert open(result).read() == "ok"
+
+
+def test_slab_layout_is_symmetric_and_avoids_the_unmappable_sizes():
+    import conftest  # noqa: F401
+    from splitwise_amd.worker.kv_comm import FLAG_BYTES, _ipc_safe_size, slab_layout
+    offsets, flags, total = slab_layout(32, 128 * 1024, 9500)
+    assert offsets == slab_layout(32, 128 * 1024, 9500)[0] and flags == total - FLAG_BYTES
+    assert offsets[0] == (0, 9500 * 128 * 1024) and offsets[1][0] == 2 * 9500 * 128 * 1024
+    for gib in (0.5, 1.0, 1.99, 2.01, 3.9, 6, 19, 23, 42.1, 64):
+        n = _ipc_safe_size(int(gib * 2 ** 30))
+        assert n >= int(gib * 2 ** 30) and n % 2 ** 32 < 2 ** 31
+    assert _ipc_safe_size(1 << 30) == 1 << 30

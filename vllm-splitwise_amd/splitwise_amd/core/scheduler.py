@@ -338,6 +338,7 @@ class Scheduler:
                  preemption_mode: Optional[PreemptionMode] = None) -> None:
         # a lone sequence is recomputed (cheaper); groups with several sequences are swapped out
         # (vllm/core/scheduler.py:467-494)
+        self.num_preemptions = getattr(self, "num_preemptions", 0) + 1
         if preemption_mode is None:
             preemption_mode = (PreemptionMode.RECOMPUTE if seq_group.get_max_num_running_seqs() == 1
                                else PreemptionMode.SWAP)

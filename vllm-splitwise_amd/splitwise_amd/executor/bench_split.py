@@ -48,6 +48,18 @@ def _kv_push_bandwidth(executor, iters: int = 6):
 
 
 def run(args, rank: int, local_rank: int, world: int) -> None:
+    """Never hangs on a failure: any exception ends this rank at once with a non-zero status (a
+    transport set-up call that is stuck inside the HIP runtime would block a normal interpreter
+    exit), and torchrun then stops the other ranks."""
+    try:
+        _run(args, rank, local_rank, world)
+    except BaseException:                      # noqa: BLE001
+        import traceback
+        traceback.print_exc()
+        os._exit(1)
+
+
+def _run(args, rank: int, local_rank: int, world: int) -> None:
     from .. import EngineArgs, LLMEngine
     from .channel import DistChannel
     from .remote_worker import worker_loop

@@ -18,11 +18,12 @@ def make_exchange(channel):
     return exchange
 
 
-def worker_loop(channel, cfg: Dict[str, Any]) -> None:
-    """cfg: model_config, parallel_config, scheduler_config, cache_config, rank, local_rank, transport."""
+def worker_loop(channel, cfg: Dict[str, Any], worker_cls=Worker) -> None:
+    """cfg: model_config, parallel_config, scheduler_config, cache_config, rank, local_rank, transport.
+    ``worker_cls`` is the worker implementation (tests drive the control plane with a CPU stand-in)."""
     worker = None
     try:
-        worker = Worker(cfg["model_config"], cfg["parallel_config"], cfg["scheduler_config"], DeviceConfig("cuda"),
+        worker = worker_cls(cfg["model_config"], cfg["parallel_config"], cfg["scheduler_config"], DeviceConfig("cuda"),
                         local_rank=cfg["local_rank"], rank=cfg["rank"], kv_cache_dtype=cfg["cache_config"].cache_dtype,
                         is_driver_worker=True,
                         kv_transport_init={"exchange": make_exchange(channel), "transport": cfg["transport"]})

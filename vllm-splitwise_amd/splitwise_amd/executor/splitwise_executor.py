@@ -25,7 +25,7 @@ class SplitwiseExecutor(ExecutorBase):
     def __init__(self, model_config: ModelConfig, cache_config: CacheConfig, parallel_config: ParallelConfig,
                  scheduler_config: SchedulerConfig, device_config: DeviceConfig,
                  num_gpu_blocks_override: Optional[int] = None, channel=None, prompt_device: int = 0,
-                 token_device: Optional[int] = None, transport: str = "kernel") -> None:
+                 token_device: Optional[int] = None, transport: str = "kernel", worker_cls=Worker) -> None:
         if not parallel_config.sep_prompt_token:
             raise ValueError("SplitwiseExecutor needs sep_prompt_token=True")
         if parallel_config.tensor_parallel_size != 1:
@@ -50,7 +50,7 @@ class SplitwiseExecutor(ExecutorBase):
             channel = PipeChannel(parent)
         self.channel = channel
         self._pending_kv: List[Any] = []
-        self.driver_worker = Worker(model_config, parallel_config, scheduler_config, device_config,
+        self.driver_worker = worker_cls(model_config, parallel_config, scheduler_config, device_config,
                                     local_rank=prompt_device, rank=0, kv_cache_dtype=cache_config.cache_dtype,
                                     is_driver_worker=True,
                                     kv_transport_init={"exchange": self._exchange, "transport": transport})

@@ -16,6 +16,7 @@ kernel); it exists as a fallback should direct peer stores from a kernel misbeha
 system.  (Inter-process HIP events are not usable for the hand-off: hipIpcGetEventHandle
 fails on this stack.)
 """
+import threading
 from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -26,6 +27,37 @@ from ..utils import MAX_SLOT_IDS
 HEAD_TYPES = [0, 1]               # 0 = keys, 1 = values (comm_utils.py:17)
 FLAG_BYTES = 4096                 # MAX_SLOT_IDS int32 flags + a status word, padded
 _MAX_SPINS = 5_000_000            # bounded wait, about 10 s
+
+
+_IPC_OPEN_TIMEOUT_S = 120.0
+
+
+class TransportSetupTimeout(RuntimeError):
+    """A HIP runtime call of the transport set-up did not return.  The stuck call keeps holding
+    runtime locks, so the process should leave with os._exit after reporting this."""
+
+
+def _bounded(fn: Callable, seconds: float, what: str):
+    """Runs ``fn`` on a helper thread and gives up after ``seconds``: a set-up call that never
+    returns must fail the worker loudly instead of hanging the whole job."""
+    box: Dict[str, object] = {}
+    device = torch.cuda.current_device()
+
+    def run() -> None:
+        try:
+            torch.cuda.set_device(device)
+            box["value"] = fn()
+        except BaseException as e:              # noqa: BLE001 - re-raised on the caller's thread
+            box["error"] = e
+
+    t = threading.Thread(target=run, daemon=True)
+    t.start()
+    t.join(seconds)
+    if t.is_alive():
+        raise TransportSetupTimeout(f"{what} did not return within {seconds:.0f} s")
+    if "error" in box:
+        raise box["error"]
+    return box["value"]
 
 
 class _DevicePtrView:
@@ -178,7 +210,8 @@ class KVCacheCommManager:
             raise RuntimeError("prompt and token workers disagree on the cache layout")
         peer_base = 0
         if self.is_prompt_side:
-            peer_base = _C.kv_ops.ipc_open_mem_handle(peer["handle"])
+            peer_base = _bounded(lambda: _C.kv_ops.ipc_open_mem_handle(peer["handle"]), _IPC_OPEN_TIMEOUT_S,
+                                 "mapping the token worker's KV cache (hipIpcOpenMemHandle)")
             self._peer_mapping = peer_base
         comm = KVCacheCommunicator(block_bytes, layer_offsets, base, peer_base, flags_offset, self.transport, device)
         if self.transport == "runtime":
