@@ -110,8 +110,13 @@ def _run(args, rank: int, local_rank: int, world: int) -> None:
     if engines is not None:
         dist.barrier(group=engines)
     t0 = time.perf_counter()
+    ctx_samples = []
     for i in range(args.steps):
         loop.step(True)
+        if i % 16 == 8 and len(ctx_samples) < 12:           # decode batches of the timed region, for the roofline
+            lens = [g.get_seqs()[0].get_len() for g in engine.scheduler.running if g.get_seqs()[0].get_output_len() > 0]
+            if lens:
+                ctx_samples.append(lens)
         if verbose and i % 20 == 0:
             print(f"[rank {rank}] step {i}", file=sys.stderr, flush=True)
     torch.cuda.synchronize()
@@ -128,6 +133,17 @@ def _run(args, rank: int, local_rank: int, world: int) -> None:
         dist.all_reduce(stats, group=engines)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX, group=engines)
     kv = _kv_push_bandwidth(executor)
+    roofline = None
+    if rank == 0 and ctx_samples:
+        prof = executor._remote_call("profile_decode_attention", samples=ctx_samples)
+        if prof["launches"]:
+            avg_s = prof["total_ms"] * 1e-3 / prof["launches"]
+            achieved = prof["alg_bytes"] / prof["launches"] / avg_s / 1e9
+            roofline = {"bound": "hbm", "kernel": "paged_attention_kernel (decode, token GPU of pair 0)",
+                        "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                        "avg_launch_us": round(avg_s * 1e6, 2), "launches_timed": prof["launches"],
+                        "alg_bytes_per_launch": int(prof["alg_bytes"] / prof["launches"])}
     executor.driver_worker.kvcache_comm_manager.check_status()
     executor.shutdown()
     if rank == 0:
@@ -148,6 +164,8 @@ def _run(args, rank: int, local_rank: int, world: int) -> None:
             "slo_attainment": round(float(stats[2]) / max(float(stats[3]), 1.0), 4),
             "kv_bytes_pushed": int(stats[4]),
             "kv_migration": kv,
+            "roofline": roofline,
+            "cpu_baseline": None,
             "ttft_p50_ms": round(sorted(ttfts)[len(ttfts) // 2] * 1e3, 2) if ttfts else None,
             "tpot_p50_ms": round(sorted(tpots)[len(tpots) // 2] * 1e3, 2) if tpots else None,
         }

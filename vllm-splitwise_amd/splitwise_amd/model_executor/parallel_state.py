@@ -20,10 +20,12 @@ _TP_RANK = 0
 def initialize_model_parallel(tensor_model_parallel_size: int = 1, sep_prompt_token: bool = False,
                               backend: Optional[str] = None) -> None:
     global _TP_GROUP, _STAGE_GROUP, _TP_WORLD, _TP_RANK
-    if not dist.is_initialized():
-        assert tensor_model_parallel_size == 1, "torch.distributed must be initialised for TP > 1"
+    if tensor_model_parallel_size == 1:
+        # pools of one GPU need no collective at all; creating one-member groups would only add
+        # rendezvous traffic (and gloo chatter on stdout) to whatever job launched the workers
         _TP_WORLD, _TP_RANK = 1, 0
         return
+    assert dist.is_initialized(), "torch.distributed must be initialised for TP > 1"
     world, rank = dist.get_world_size(), dist.get_rank()
     assert world % tensor_model_parallel_size == 0
     for i in range(world // tensor_model_parallel_size):

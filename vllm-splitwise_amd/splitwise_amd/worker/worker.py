@@ -237,5 +237,47 @@ class Worker:
     def vocab_size(self) -> int:
         return self.model_runner.vocab_size
 
+    @torch.inference_mode()
+    def profile_decode_attention(self, samples: List[List[int]]) -> Dict[str, float]:
+        """Measurement aid: times the decode paged-attention launch of every layer over this worker's
+        own cache for batches with the given context lengths (block tables drawn at random from the
+        cache), with HIP events on the launch stream.  -> total ms, launches, algorithmic bytes."""
+        from ..model_executor.input_metadata import InputMetadata
+        from ..model_executor.layers.attention import PagedAttentionImpl
+        cfg, par = self.model_config, self.parallel_config
+        h = cfg.hf_config["num_attention_heads"] // par.tensor_parallel_size
+        kvh, d = cfg.get_num_kv_heads(par), cfg.get_head_size()
+        kc0 = self.gpu_cache[0][0]
+        es, bs, nb = kc0.element_size(), self.cache_config.block_size, kc0.shape[0]
+        scale = d ** -0.5
+        stream = torch.cuda.current_stream(self.device)
+        gen = torch.Generator(device="cpu").manual_seed(0)
+        total_ms, launches, alg_bytes = 0.0, 0, 0.0
+        for lens in samples:
+            n = len(lens)
+            if n == 0:
+                continue
+            max_blocks = max(-(-c // bs) for c in lens)
+            tables = torch.randint(0, nb, (n, max_blocks), generator=gen, dtype=torch.int32).to(self.device)
+            ctx = torch.tensor(lens, dtype=torch.int32, device=self.device)
+            md = InputMetadata(is_prompt=False, slot_mapping=torch.empty(0, dtype=torch.long, device=self.device),
+                               prompt_lens=None, max_seq_len=None, start_loc=None, max_context_len=max(lens),
+                               context_lens=ctx, block_tables=tables, use_cuda_graph=False,
+                               kv_cache_dtype=self.cache_config.cache_dtype)
+            q = torch.empty(n, h, d, dtype=cfg.dtype, device=self.device).uniform_(-scale, scale)
+            for kc, vc in self.gpu_cache[:2]:
+                PagedAttentionImpl.forward_decode(q, kc, vc, md, kvh, scale, None)
+            start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            start.record(stream)
+            for kc, vc in self.gpu_cache:
+                PagedAttentionImpl.forward_decode(q, kc, vc, md, kvh, scale, None)
+            end.record(stream)
+            end.synchronize()
+            total_ms += start.elapsed_time(end)
+            launches += len(self.gpu_cache)
+            alg_bytes += (2.0 * sum(lens) * kvh * d * es + 2.0 * n * h * d * q.element_size() + tables.numel() * 4) * len(
+                self.gpu_cache)
+        return {"total_ms": total_ms, "launches": launches, "alg_bytes": alg_bytes}
+
     def get_cache_block_size_bytes(self, block_size: int, cache_dtype: str) -> int:
         return CacheEngine.get_cache_block_size(block_size, cache_dtype, self.model_config, self.parallel_config)
