@@ -199,6 +199,8 @@ int launch_rms(void* out, void* input, void* residual, const void* weight, float
     case 3: case 4: rms_norm_kernel<act_t, FUSED, 4><<<grid, kEwThreads, 0, stream>>>(o, in, res, w, eps, hidden, in_stride); break;
     case 5: case 6: case 7: case 8:
       rms_norm_kernel<act_t, FUSED, 8><<<grid, kEwThreads, 0, stream>>>(o, in, res, w, eps, hidden, in_stride); break;
+    case 9: case 10: case 11: case 12: case 13: case 14: case 15: case 16:
+      rms_norm_kernel<act_t, FUSED, 16><<<grid, kEwThreads, 0, stream>>>(o, in, res, w, eps, hidden, in_stride); break;
     default:
       set_error("rms_norm: hidden size %d too large", hidden);
       return SW_ERR_INVALID;
