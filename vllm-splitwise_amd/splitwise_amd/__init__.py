@@ -6,6 +6,7 @@ through :mod:`splitwise_amd._C`.  The public names are the reference's (vllm/__i
 __version__ = "0.1.0"
 
 from .engine.arg_utils import EngineArgs          # noqa: E402,F401
+from .engine.async_llm_engine import AsyncLLMEngine   # noqa: E402,F401
 from .engine.llm_engine import LLMEngine          # noqa: E402,F401
 from .entrypoints.llm import LLM                  # noqa: E402,F401
 from .outputs import CompletionOutput, RequestOutput   # noqa: E402,F401
