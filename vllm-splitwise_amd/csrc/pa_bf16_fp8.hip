@@ -3,5 +3,5 @@
 #include "paged_attention.cuh"
 
 namespace sw {
-int pa_dispatch_bf16_fp8(const PaArgs& a) { return dispatch_pa<bf16_t, true, true>(a); }
+int pa_dispatch_bf16_fp8(const PaArgs& a) { return dispatch_pa<bf16_t, true, 2>(a); }
 }  // namespace sw

@@ -3,5 +3,5 @@
 #include "paged_attention.cuh"
 
 namespace sw {
-int pa_dispatch_f16(const PaArgs& a) { return dispatch_pa<f16_t, false, true>(a); }
+int pa_dispatch_f16(const PaArgs& a) { return dispatch_pa<f16_t, false, 8>(a); }
 }  // namespace sw

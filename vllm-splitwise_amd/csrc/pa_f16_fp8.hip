@@ -3,5 +3,5 @@
 #include "paged_attention.cuh"
 
 namespace sw {
-int pa_dispatch_f16_fp8(const PaArgs& a) { return dispatch_pa<f16_t, true, true>(a); }
+int pa_dispatch_f16_fp8(const PaArgs& a) { return dispatch_pa<f16_t, true, 8>(a); }
 }  // namespace sw

@@ -3,5 +3,5 @@
 #include "paged_attention.cuh"
 
 namespace sw {
-int pa_dispatch_f32(const PaArgs& a) { return dispatch_pa<float, false, false>(a); }
+int pa_dispatch_f32(const PaArgs& a) { return dispatch_pa<float, false, 1>(a); }
 }  // namespace sw

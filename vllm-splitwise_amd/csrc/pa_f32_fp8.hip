@@ -3,5 +3,5 @@
 #include "paged_attention.cuh"
 
 namespace sw {
-int pa_dispatch_f32_fp8(const PaArgs& a) { return dispatch_pa<float, true, false>(a); }
+int pa_dispatch_f32_fp8(const PaArgs& a) { return dispatch_pa<float, true, 1>(a); }
 }  // namespace sw

@@ -25,6 +25,7 @@
 
 #include "common.cuh"
 #include <float.h>
+#include <stdlib.h>
 
 namespace sw {
 
@@ -40,9 +41,9 @@ struct CacheTraits {
   static constexpr int X = 16 / CS;
 };
 
-// largest divisor of n that is <= 16
-constexpr int key_batch(int n) {
-  int b = n < 16 ? n : 16;
+// largest divisor of n that is <= cap
+constexpr int key_batch(int n, int cap = 16) {
+  int b = n < cap ? n : cap;
   while (n % b) --b;
   return b;
 }
@@ -69,6 +70,47 @@ __device__ __forceinline__ void unpack_act(const uint32_t* w, float* out) {
   unpack_cache<act_t, false, N>(w, out);
 }
 
+// Packed 16-bit path: q, k, p and v stay as (even, odd) element pairs in one dword and go through
+// v_dot2_f32_f16 / v_dot2c_f32_bf16 (two multiply-adds per instruction, fp32 accumulation), so
+// no element is ever unpacked to fp32.
+using h16x2 = __attribute__((ext_vector_type(2))) _Float16;
+using b16x2 = __attribute__((ext_vector_type(2))) __bf16;
+
+template <typename act_t> struct Dot2 { static constexpr bool kAvailable = false; };
+template <> struct Dot2<f16_t> {
+  static constexpr bool kAvailable = true;
+  __device__ static __forceinline__ float run(uint32_t a, uint32_t b, float c) {
+    return __builtin_amdgcn_fdot2(__builtin_bit_cast(h16x2, a), __builtin_bit_cast(h16x2, b), c, false);
+  }
+};
+template <> struct Dot2<bf16_t> {
+  static constexpr bool kAvailable = true;
+  __device__ static __forceinline__ float run(uint32_t a, uint32_t b, float c) {
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(b16x2, a), __builtin_bit_cast(b16x2, b), c, false);
+  }
+};
+
+// N cache elements (N/2 pairs) -> dwords of activation-dtype pairs.  fp8 e5m2 is the high byte of
+// a half, so a byte moves to the high half of its 16-bit lane (f16 activations only).
+template <bool FP8, int N>
+__device__ __forceinline__ void cache_pairs(const uint32_t* w, uint32_t* out) {
+  if constexpr (FP8) {
+#pragma unroll
+    for (int i = 0; i < N / 4; ++i) {
+      out[2 * i] = __builtin_amdgcn_perm(0u, w[i], 0x010c000cu);       // bytes [0, b0, 0, b1]
+      out[2 * i + 1] = __builtin_amdgcn_perm(0u, w[i], 0x030c020cu);   // bytes [0, b2, 0, b3]
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < N / 2; ++i) out[i] = w[i];
+  }
+}
+
+// 16-bit cache of the activation dtype, or an fp8 cache under f16 activations (bf16 has no exact
+// byte move from e5m2 and keeps the fp32 path)
+template <typename act_t, bool FP8> struct PackedPath { static constexpr bool value = Dot2<act_t>::kAvailable && !FP8; };
+template <> struct PackedPath<f16_t, true> { static constexpr bool value = true; };
+
 template <typename act_t, bool FP8, int HEAD, int BS, int QG>
 __global__ void __launch_bounds__(kPaThreads)
 paged_attention_kernel(void* __restrict__ out_,            // v1: [S,H,HEAD]; v2: tmp_out [S,H,P,HEAD]
@@ -84,7 +126,8 @@ paged_attention_kernel(void* __restrict__ out_,            // v1: [S,H,HEAD]; v2
   using S = typename T::S;
   constexpr int ES = T::ES, CS = T::CS, X = T::X;
   constexpr int NCH = HEAD / X;                    // 16-byte key pieces per token
-  constexpr int KB = key_batch(NCH);               // key pieces in flight per batch
+  // key pieces in flight per batch; several query heads per workgroup leave fewer registers
+  constexpr int KB = key_batch(NCH, QG >= 4 ? 4 : 16);
   constexpr int NB = 64 / BS;                      // cache blocks per 64-token group
   constexpr int VT = (16 / CS) < BS ? (16 / CS) : BS;   // tokens per V piece
   constexpr int VBYTES = VT * CS;                  // 16 (or 8: fp8 cache, block 8)
@@ -92,6 +135,7 @@ paged_attention_kernel(void* __restrict__ out_,            // v1: [S,H,HEAD]; v2
   constexpr int UNITS = HEAD * UPR;                // V pieces per [block, head] tile
   constexpr int NIT = (UNITS + 63) / 64;           // V pieces per lane per block
   constexpr int PW = VT * ES / 4;                  // dwords of probabilities per V piece
+  constexpr bool PACKED = PackedPath<act_t, FP8>::value;
   static_assert(HEAD % X == 0 && NCH % KB == 0, "head size must split into key batches");
   static_assert(64 % BS == 0 && BS % VT == 0, "block size must divide the 64-token group");
 
@@ -119,9 +163,16 @@ paged_attention_kernel(void* __restrict__ out_,            // v1: [S,H,HEAD]; v2
   const int num_ctx_blocks = (ctx + BS - 1) / BS;
 
   // ---- query -> LDS as fp32, pre-multiplied by nothing (scale is applied to the dot)
+  const uint32_t* q_p = reinterpret_cast<const uint32_t*>(smem);           // packed path: [QG][HEAD/2] pairs
   {
     const S* q = reinterpret_cast<const S*>(q_) + seq * q_stride + (int64_t)head0 * HEAD;
-    for (int i = tid; i < QG * HEAD; i += kPaThreads) q_s[i] = Conv<act_t>::to_float(q[i]);
+    if constexpr (PACKED) {
+      uint32_t* dst = reinterpret_cast<uint32_t*>(smem);
+      const uint32_t* src = reinterpret_cast<const uint32_t*>(q);          // 4-byte aligned: checked on the host
+      for (int i = tid; i < QG * HEAD / 2; i += kPaThreads) dst[i] = src[i];
+    } else {
+      for (int i = tid; i < QG * HEAD; i += kPaThreads) q_s[i] = Conv<act_t>::to_float(q[i]);
+    }
   }
   __syncthreads();
 
@@ -170,6 +221,22 @@ paged_attention_kernel(void* __restrict__ out_,            // v1: [S,H,HEAD]; v2
           kraw[c] = *reinterpret_cast<const uint4*>(kp + (int64_t)(cb + c) * BS * 16);
 #pragma unroll
         for (int c = 0; c < KB; ++c) {
+          if constexpr (PACKED) {
+            uint32_t kp2[X / 2];
+            cache_pairs<FP8, X>(reinterpret_cast<const uint32_t*>(&kraw[c]), kp2);
+#pragma unroll
+            for (int h = 0; h < QG; ++h) {
+              const uint32_t* qh = q_p + h * (HEAD / 2) + (cb + c) * (X / 2);
+#pragma unroll
+              for (int e = 0; e < X / 2; e += 4) {
+                const uint4 qv = *reinterpret_cast<const uint4*>(qh + e);     // LDS broadcast
+                qk[h] = Dot2<act_t>::run(qv.x, kp2[e], qk[h]);
+                qk[h] = Dot2<act_t>::run(qv.y, kp2[e + 1], qk[h]);
+                qk[h] = Dot2<act_t>::run(qv.z, kp2[e + 2], qk[h]);
+                qk[h] = Dot2<act_t>::run(qv.w, kp2[e + 3], qk[h]);
+              }
+            }
+          } else {
           float kf[X];
           unpack_cache<act_t, FP8, X>(reinterpret_cast<const uint32_t*>(&kraw[c]), kf);
 #pragma unroll
@@ -183,6 +250,7 @@ paged_attention_kernel(void* __restrict__ out_,            // v1: [S,H,HEAD]; v2
               qk[h] = fmaf(qv.z, kf[e + 2], qk[h]);
               qk[h] = fmaf(qv.w, kf[e + 3], qk[h]);
             }
+          }
           }
         }
       }
@@ -235,6 +303,37 @@ paged_attention_kernel(void* __restrict__ out_,            // v1: [S,H,HEAD]; v2
       for (int it = 0; it < NIT; ++it) {
         const int u = it * 64 + lane;
         const int part = u % UPR;                           // which VT-token slice of the row
+        if constexpr (PACKED) {
+          uint32_t vp2[VT / 2];
+          cache_pairs<FP8, VT>(vraw[it], vp2);
+          if (last_block) {
+            // zero V of tokens past the context (they may hold NaNs); their p is 0 too
+#pragma unroll
+            for (int j = 0; j < VT / 2; ++j) {
+              const int tok = btok0 + part * VT + 2 * j;
+              vp2[j] &= (tok < ctx ? 0x0000ffffu : 0u) | (tok + 1 < ctx ? 0xffff0000u : 0u);
+            }
+          }
+#pragma unroll
+          for (int h = 0; h < QG; ++h) {
+            const uint32_t* pp = reinterpret_cast<const uint32_t*>(p_w + h * 64 + b * BS + part * VT);
+            float a = acc[h][it];
+            if constexpr (VT / 2 >= 4) {
+#pragma unroll
+              for (int w4 = 0; w4 < VT / 2; w4 += 4) {
+                const uint4 t = *reinterpret_cast<const uint4*>(pp + w4);
+                a = Dot2<act_t>::run(t.x, vp2[w4], a);
+                a = Dot2<act_t>::run(t.y, vp2[w4 + 1], a);
+                a = Dot2<act_t>::run(t.z, vp2[w4 + 2], a);
+                a = Dot2<act_t>::run(t.w, vp2[w4 + 3], a);
+              }
+            } else {
+#pragma unroll
+              for (int w = 0; w < VT / 2; ++w) a = Dot2<act_t>::run(pp[w], vp2[w], a);
+            }
+            acc[h][it] = a;
+          }
+        } else {
         float vf[VT];
         unpack_cache<act_t, FP8, VT>(vraw[it], vf);
         if (last_block) {
@@ -264,6 +363,7 @@ paged_attention_kernel(void* __restrict__ out_,            // v1: [S,H,HEAD]; v2
 #pragma unroll
           for (int j = 0; j < VT; ++j) a = fmaf(pf[j], vf[j], a);
           acc[h][it] = a;
+        }
         }
       }
     }
@@ -403,15 +503,19 @@ int launch_pa(const PaArgs& a) {
 }
 
 // Dispatch over head size / block size / query-group width for one (act, cache) pair.
-// Query-group widths above 1 are built for head sizes 64 and 128 and blocks of 16 / 32.
-template <typename act_t, bool FP8, bool WIDE>
+// Query-group widths above 1 are built for head sizes 64 and 128 and blocks of 16 / 32, up to
+// MAXQG query heads per workgroup: the widest width whose kernel still fits the register file
+// without spilling (f16: 8; bf16: 4, its two-address dot instruction costs registers; bf16 over an
+// fp8 cache, which takes the fp32 path: 2).
+template <typename act_t, bool FP8, int MAXQG>
 int dispatch_pa(const PaArgs& a) {
   const int g = a.num_heads / a.num_kv_heads;
   int qg = 1;
-  if (WIDE && (a.head_size == 64 || a.head_size == 128) && a.block_size >= 16) {
+  if (MAXQG > 1 && (a.head_size == 64 || a.head_size == 128) && a.block_size >= 16) {
     if (g % 8 == 0) qg = 8;
     else if (g % 4 == 0) qg = 4;
     else if (g % 2 == 0) qg = 2;
+    while (qg > MAXQG) qg /= 2;
   }
 #define SW_PA_BS(HEAD, QG)                                                       \
   switch (a.block_size) {                                                        \
@@ -422,12 +526,10 @@ int dispatch_pa(const PaArgs& a) {
   }                                                                              \
   set_error("Unsupported block size: %d", a.block_size);                         \
   return SW_ERR_INVALID;
-#define SW_PA_QG(HEAD)                              \
-  if constexpr (WIDE) {                             \
-    if (qg == 8) { SW_PA_BS(HEAD, 8) }              \
-    if (qg == 4) { SW_PA_BS(HEAD, 4) }              \
-    if (qg == 2) { SW_PA_BS(HEAD, 2) }              \
-  }                                                 \
+#define SW_PA_QG(HEAD)                                        \
+  if constexpr (MAXQG >= 8) { if (qg == 8) { SW_PA_BS(HEAD, 8) } } \
+  if constexpr (MAXQG >= 4) { if (qg == 4) { SW_PA_BS(HEAD, 4) } } \
+  if constexpr (MAXQG >= 2) { if (qg == 2) { SW_PA_BS(HEAD, 2) } } \
   { SW_PA_BS(HEAD, 1) }
   switch (a.head_size) {
     case 64: { SW_PA_QG(64) }

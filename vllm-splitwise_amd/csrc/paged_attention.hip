@@ -19,6 +19,9 @@ static int run_paged_attention(PaArgs& a, int act_dtype, int cache_dtype) {
   SW_CHECK_ARG((a.kv_block_stride * cs) % 16 == 0 && (a.kv_head_stride * cs) % 16 == 0 &&
                    reinterpret_cast<uintptr_t>(a.k) % 16 == 0 && reinterpret_cast<uintptr_t>(a.v) % 16 == 0,
                "paged_attention: cache strides / base must be 16-byte aligned");
+  // 16-bit queries are read as (even, odd) pairs
+  SW_CHECK_ARG(dtype_size(act_dtype) != 2 || (a.q_stride % 2 == 0 && reinterpret_cast<uintptr_t>(a.q) % 4 == 0),
+               "paged_attention: query rows must be 4-byte aligned");
   SW_CHECK_ARG(a.max_context_len > 0 && a.max_num_blocks_per_seq > 0, "paged_attention: empty context");
   if (a.partitioned) {
     SW_CHECK_ARG(a.exp_sums && a.max_logits && a.tmp_out, "paged_attention_v2: missing temporaries");

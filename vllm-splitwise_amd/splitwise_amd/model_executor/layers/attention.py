@@ -35,15 +35,34 @@ class PagedAttentionImpl:
                                        input_metadata.kv_cache_dtype)
 
     @staticmethod
-    def use_v1(num_seqs: int, num_heads: int, num_kv_heads: int, max_context_len: int) -> bool:
-        """One workgroup serves a (sequence, kv head) pair -- all query heads of a GQA group at
-        once -- so the unpartitioned kernel fills the 256 CUs only with enough such pairs; below
-        that the context is split into 512-token partitions (v2).  (The reference's rule,
-        ops/paged_attn.py:62-63, is tuned for 128-thread blocks per query head and a shared-memory
-        cap that does not exist here.)"""
+    def query_group_width(num_heads: int, num_kv_heads: int, head_size: int, block_size: int,
+                          dtype: torch.dtype, kv_cache_dtype: str) -> int:
+        """Query heads one workgroup of the decode kernel serves from a single pass over K and V
+        (the dispatch rule of csrc/paged_attention.cuh: powers of two up to 8 for f16, 4 for bf16,
+        2 for bf16 over an fp8 cache, 1 for fp32; head sizes 64 / 128 and blocks of 16 / 32 only)."""
+        if head_size not in (64, 128) or block_size < 16:
+            return 1
+        cap = {torch.float16: 8, torch.bfloat16: 2 if kv_cache_dtype == "fp8_e5m2" else 4}.get(dtype, 1)
+        group = num_heads // num_kv_heads
+        width = 8 if group % 8 == 0 else 4 if group % 4 == 0 else 2 if group % 2 == 0 else 1
+        return min(width, cap)
+
+    @staticmethod
+    def use_v1(num_seqs: int, num_heads: int, num_kv_heads: int, max_context_len: int, query_group: int = 1) -> bool:
+        """The unpartitioned kernel launches one workgroup per (sequence, group of ``query_group``
+        query heads); it fills the 256 CUs only with enough of them, below that the context is
+        split into 512-token partitions (v2).  Thresholds measured on MI355X for MHA, GQA and fp8
+        shapes (1..256 sequences, 768..16384 tokens).  (The reference's rule, ops/paged_attn.py:62-63,
+        is tuned for 128-thread blocks per query head and a shared-memory cap that does not exist
+        here.)"""
         if max_context_len <= _PARTITION_SIZE:
             return True
-        return num_seqs * num_kv_heads >= 1024
+        workgroups = num_seqs * num_heads // max(query_group, 1)
+        if workgroups >= 512:
+            return True
+        if workgroups >= 256 and max_context_len < 4096:
+            return True
+        return workgroups >= 32 and max_context_len <= 2 * _PARTITION_SIZE
 
     @staticmethod
     def forward_decode(query, key_cache, value_cache, input_metadata: InputMetadata, num_kv_heads: int,
@@ -52,7 +71,9 @@ class PagedAttentionImpl:
         block_size = value_cache.shape[3]
         num_seqs, num_heads, head_size = query.shape
         max_ctx = input_metadata.max_context_len
-        if PagedAttentionImpl.use_v1(num_seqs, num_heads, num_kv_heads, max_ctx):
+        width = PagedAttentionImpl.query_group_width(num_heads, num_kv_heads, head_size, block_size, query.dtype,
+                                                     input_metadata.kv_cache_dtype)
+        if PagedAttentionImpl.use_v1(num_seqs, num_heads, num_kv_heads, max_ctx, width):
             _C.ops.paged_attention_v1(output, query, key_cache, value_cache, num_kv_heads, scale,
                                       input_metadata.block_tables, input_metadata.context_lens, block_size,
                                       max_ctx, alibi_slopes, input_metadata.kv_cache_dtype)
