@@ -171,7 +171,10 @@ class SchedulerConfig:
     """vllm/config.py:474-520."""
 
     def __init__(self, max_num_batched_tokens: Optional[int], max_num_seqs: int, max_model_len: int,
-                 max_paddings: int = 256) -> None:
+                 max_paddings: int = 256, prefill_batch_tokens: int = 0, prefill_max_wait: float = 0.1) -> None:
+        # prefill batching (0 = off: prompts are admitted as soon as they fit, as in the reference)
+        self.prefill_batch_tokens = prefill_batch_tokens
+        self.prefill_max_wait = prefill_max_wait
         if max_num_batched_tokens is None:
             max_num_batched_tokens = max(max_model_len, 2048)
         self.max_num_batched_tokens = max_num_batched_tokens

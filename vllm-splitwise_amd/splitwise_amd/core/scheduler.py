@@ -127,11 +127,32 @@ class Scheduler:
             slot = self.seq_to_slot_mapper.get_slot_id(seq.seq_id)
             blocks_to_nw[slot].extend(self.block_manager.get_block_table(seq))
 
+    def _hold_prompts(self) -> bool:
+        """Optional prefill batching (off by default; the reference admits a prompt the moment it
+        fits): while sequences are decoding, waiting prompts are held until at least
+        ``prefill_batch_tokens`` tokens of them have gathered or the oldest has waited
+        ``prefill_max_wait`` seconds, so that a prompt step runs GEMMs of several prompts' rows."""
+        cfg = self.scheduler_config
+        want = getattr(cfg, "prefill_batch_tokens", 0)
+        if want <= 0 or not self.waiting or not self.running:
+            return False
+        waited = time.monotonic() - self.waiting[0].metrics.arrival_time
+        if waited < 0 or waited >= cfg.prefill_max_wait:
+            return False
+        have = 0
+        for group in self.waiting:
+            have += group.get_seqs()[0].get_len()
+            if have >= want:
+                return False
+        return True
+
     def _admit_prompts(self, blocks_to_nw: Dict[int, List[int]]):
         """-> (scheduled groups, ignored groups, padded token count)."""
         cfg = self.scheduler_config
         scheduled: List[SequenceGroup] = []
         ignored: List[SequenceGroup] = []
+        if self._hold_prompts():
+            return scheduled, ignored, 0
         num_curr_seqs = sum(g.get_max_num_running_seqs() for g in self.running)
         num_prompts, longest = 0, 0
         total_len = 0

@@ -26,6 +26,8 @@ class EngineArgs:
     max_num_batched_tokens: Optional[int] = None
     max_num_seqs: int = 256
     max_paddings: int = 256
+    prefill_batch_tokens: int = 0
+    prefill_max_wait: float = 0.1
     quantization: Optional[str] = None
     enforce_eager: bool = False
     max_context_len_to_capture: Optional[int] = None
@@ -59,5 +61,6 @@ class EngineArgs:
                                          self.sep_prompt_token)
         model_config.verify_with_parallel_config(parallel_config)
         scheduler_config = SchedulerConfig(self.max_num_batched_tokens, self.max_num_seqs,
-                                           model_config.max_model_len, self.max_paddings)
+                                           model_config.max_model_len, self.max_paddings,
+                                           self.prefill_batch_tokens, self.prefill_max_wait)
         return model_config, cache_config, parallel_config, scheduler_config, DeviceConfig(self.device)

@@ -83,7 +83,8 @@ def _run(args, rank: int, local_rank: int, world: int) -> None:
     engine_args = EngineArgs(model=args.model, sep_prompt_token=True, max_num_seqs=conc, max_model_len=2048,
                              max_num_batched_tokens=args.max_num_batched_tokens,
                              num_gpu_blocks_override=int(conc * seq_blocks * 1.25) + 64, swap_space=0.25,
-                             enforce_eager=args.enforce_eager, max_context_len_to_capture=1024)
+                             enforce_eager=args.enforce_eager, max_context_len_to_capture=1024,
+                             prefill_batch_tokens=args.prefill_batch_tokens, prefill_max_wait=args.prefill_max_wait)
     mc, cc, pc, sc, dc = engine_args.create_engine_configs()
     transport = os.environ.get("SPLITWISE_KV_TRANSPORT", "kernel")
 
