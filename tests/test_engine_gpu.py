@@ -100,3 +100,37 @@ def test_padded_and_packed_prompt_layouts_agree():
         assert torch.equal(va[:used].view(torch.int16), vb[:used].view(torch.int16))
     del llm
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("split", [False, True])
+def test_tensor_parallel_pools_match_cpu_model(split, monkeypatch):
+    """Two tensor-parallel ranks per pool (co-located, then a prompt pool pushing its KV shards to a
+    token pool: four worker processes), all on this one GPU with gloo standing in for RCCL.  The
+    sharded model is the same seeded model as the unsharded one, so the whole-model CPU oracle on
+    the full weights judges the tokens."""
+    from splitwise_amd import LLM, SamplingParams
+    from splitwise_amd.config import ModelConfig
+    from splitwise_amd.model_executor.model_loader import get_model
+    monkeypatch.setenv("SPLITWISE_TP_BACKEND", "gloo")
+    random.seed(3)
+    llm = LLM("llama-tiny", tensor_parallel_size=2, sep_prompt_token=split, num_gpu_blocks_override=128,
+              max_num_seqs=8, max_model_len=512, swap_space=0.01)
+    try:
+        vocab = llm.llm_engine.model_config.get_vocab_size()
+        prompts = [[random.randrange(vocab) for _ in range(n)] for n in (5, 33, 64, 17, 100, 1, 48)]
+        outs = llm.generate(prompt_token_ids=prompts, sampling_params=SamplingParams(temperature=0.0, max_tokens=16))
+        cfg = llm.llm_engine.model_config.hf_config
+    finally:
+        llm.llm_engine.model_executor.shutdown()       # also leaves the tensor-parallel state of this process
+        del llm
+        torch.cuda.empty_cache()
+    # the unsharded model of the same seed (built on the GPU: the seeded generator is the device's)
+    full = get_model(ModelConfig("llama-tiny"), torch.device("cuda"))
+    sd = {k: v.detach().cpu() for k, v in full.state_dict().items()}
+    for prompt, out in zip(prompts, outs):
+        gen = out.outputs[0].token_ids
+        assert len(gen) == 16
+        ref = omodel.logits(cfg["architecture"], sd, cfg, prompt + gen)
+        for j, tok in enumerate(gen):
+            row = ref[len(prompt) + j - 1]
+            assert row[tok] >= row.max() - 3e-2, (j, tok, int(row.argmax()), float(row.max() - row[tok]))

@@ -33,7 +33,10 @@ class LLMEngine:
             self.model_executor = executor
         else:
             if executor_class is None:
-                if parallel_config.world_size > 1:
+                if parallel_config.tensor_parallel_size > 1:
+                    from ..executor.pool_executor import PoolExecutor
+                    executor_class = PoolExecutor
+                elif parallel_config.world_size > 1:
                     from ..executor.splitwise_executor import SplitwiseExecutor
                     executor_class = SplitwiseExecutor
                 else:

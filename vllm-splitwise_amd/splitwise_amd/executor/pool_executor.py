@@ -1,0 +1,214 @@
+"""Executor for pools of tensor-parallel workers, co-located or split.
+
+World layout of vllm/config.py:433-443 and vllm/executor/ray_gpu_executor.py:87-232: without
+``sep_prompt_token`` one MIXED pool of ``tensor_parallel_size`` ranks; with it a prompt pool
+(ranks 0..tp-1) followed by a token pool (ranks tp..2tp-1), rank i pushing its shard of the KV
+cache to rank i+tp.  One process per GPU: rank 0 lives in the engine process, every other rank is
+a child process running the worker command loop; TP collectives are RCCL's (torch.distributed
+"nccl") inside each pool.
+
+Differences from the reference, both deliberate:
+  * no Ray and no per-step tensor broadcast: every rank of a pool receives the same small step
+    command (sequence metadata, block operations) over its control channel and prepares its own
+    input tensors, so there is no driver-to-follower tensor traffic at all; only the first rank
+    of a pool reports the sampled tokens;
+  * with split pools, ``execute_split`` runs a prompt step and a decode step at the same time.
+"""
+import socket
+from typing import Any, Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from ..config import CacheConfig, DeviceConfig, ModelConfig, ParallelConfig, SchedulerConfig
+from ..sequence import SamplerOutput, SequenceGroupMetadata
+from ..worker.worker import Worker
+from .channel import PipeChannel
+from .executor_base import ExecutorBase
+from .gpu_executor import check_block_budget
+
+
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+class PoolExecutor(ExecutorBase):
+    def __init__(self, model_config: ModelConfig, cache_config: CacheConfig, parallel_config: ParallelConfig,
+                 scheduler_config: SchedulerConfig, device_config: DeviceConfig,
+                 num_gpu_blocks_override: Optional[int] = None, devices: Optional[Sequence[int]] = None,
+                 transport: str = "kernel", worker_cls=Worker, channels: Optional[Dict[int, Any]] = None) -> None:
+        self.model_config = model_config
+        self.cache_config = cache_config
+        self.parallel_config = parallel_config
+        self.scheduler_config = scheduler_config
+        self.transport = transport
+        self.tp = parallel_config.tensor_parallel_size
+        self.split = parallel_config.sep_prompt_token
+        self.world = parallel_config.world_size
+        if self.tp > 1 and not model_config.enforce_eager:
+            # collectives inside captured HIP graphs are not exercised by this build
+            model_config.enforce_eager = True
+        if devices is None:
+            n = max(torch.cuda.device_count(), 1)
+            devices = [r % n for r in range(self.world)]
+        self.devices = list(devices)
+        init_method = f"tcp://127.0.0.1:{_free_port()}" if self.tp > 1 else None
+        self.processes = []
+        self.channels: Dict[int, Any] = dict(channels or {})
+        if not self.channels and self.world > 1:
+            import torch.multiprocessing as mp
+            from .remote_worker import spawn_entry
+            ctx = mp.get_context("spawn")
+            for rank in range(1, self.world):
+                parent, child = ctx.Pipe(duplex=True)
+                proc = ctx.Process(target=spawn_entry, args=(child, self._remote_cfg(rank, init_method)), daemon=True)
+                proc.start()
+                child.close()
+                self.processes.append(proc)
+                self.channels[rank] = PipeChannel(parent)
+        transport_init = {"exchange": self._exchange, "transport": transport} if self.split else None
+        extra = {"distributed_init_method": init_method} if init_method else {}
+        self.driver_worker = worker_cls(model_config, parallel_config, scheduler_config, device_config,
+                                        local_rank=self.devices[0], rank=0, kv_cache_dtype=cache_config.cache_dtype,
+                                        is_driver_worker=True, kv_transport_init=transport_init, **extra)
+        self.all_ranks = list(range(self.world))
+        self.prompt_pool = list(range(self.tp))
+        self.token_pool = list(range(self.tp, 2 * self.tp)) if self.split else self.prompt_pool
+        self._call_all(self.all_ranks, "init_model")
+        self._call_all(self.all_ranks, "load_model")
+        self._init_cache(num_gpu_blocks_override)
+
+    def _remote_cfg(self, rank: int, init_method: Optional[str]) -> Dict[str, Any]:
+        return {"model_config": self.model_config, "parallel_config": self.parallel_config,
+                "scheduler_config": self.scheduler_config, "cache_config": self.cache_config, "rank": rank,
+                "local_rank": self.devices[rank], "transport": self.transport,
+                "distributed_init_method": init_method, "reports_output": rank % self.tp == 0}
+
+    # ------------------------------------------------------------ control plane
+    def _send(self, rank: int, name: str, kwargs: dict) -> None:
+        self.channels[rank].send(("execute", kwargs) if name == "execute_model" else ("call", name, kwargs))
+
+    def _wait(self, rank: int):
+        status, result = self.channels[rank].recv()
+        if status != "ok":
+            raise RuntimeError(f"worker {rank} failed: {result}")
+        return result
+
+    def _call_all(self, ranks: List[int], name: str, **kwargs) -> Dict[int, Any]:
+        """Starts ``name`` on every remote rank, runs it on the local one, waits for all."""
+        remote = [r for r in ranks if r != 0]
+        for r in remote:
+            self._send(r, name, kwargs)
+        results: Dict[int, Any] = {}
+        if 0 in ranks:
+            results[0] = getattr(self.driver_worker, name)(**kwargs)
+        for r in remote:
+            results[r] = self._wait(r)
+        return results
+
+    def _exchange(self, obj):
+        """One round of the KV-transport handshake: every worker hands in one object and gets its
+        pair's.  Runs inside the local prompt worker's set-up, which is when the others ask too."""
+        for i in range(1, self.tp):                         # pairs that live entirely in other processes
+            tag_a, a = self.channels[i].recv()
+            tag_b, b = self.channels[i + self.tp].recv()
+            assert tag_a == tag_b == "kv_exchange", (tag_a, tag_b)
+            self.channels[i].send(("kv_exchange", b))
+            self.channels[i + self.tp].send(("kv_exchange", a))
+        tag, peer = self.channels[self.tp].recv()           # the local worker's own pair
+        assert tag == "kv_exchange", tag
+        self.channels[self.tp].send(("kv_exchange", obj))
+        return peer
+
+    # -------------------------------------------------------------------- cache
+    def _init_cache(self, override: Optional[int]) -> None:
+        cc = self.cache_config
+        if override is None:
+            sizes = self._call_all(self.all_ranks, "profile_num_available_blocks", block_size=cc.block_size,
+                                   gpu_memory_utilization=cc.gpu_memory_utilization,
+                                   cpu_swap_space=cc.swap_space_bytes, cache_dtype=cc.cache_dtype)
+            # a block id means the same block on every rank: all caches get the smallest size
+            num_gpu_blocks = min(s[0] for s in sizes.values())
+            num_cpu_blocks = min(s[1] for s in sizes.values())
+        else:
+            per_block = self.driver_worker.get_cache_block_size_bytes(cc.block_size, cc.cache_dtype)
+            num_gpu_blocks, num_cpu_blocks = override, int(cc.swap_space_bytes // per_block)
+        check_block_budget(self.model_config.max_model_len, cc.block_size, num_gpu_blocks)
+        cc.num_gpu_blocks, cc.num_cpu_blocks = num_gpu_blocks, num_cpu_blocks
+        self._call_all(self.all_ranks, "init_cache_engine", cache_config=cc)
+        self._call_all(self.all_ranks, "warm_up_model")
+        if self.split:
+            self._call_all(self.all_ranks, "setup_kvcache_comm")
+
+    # --------------------------------------------------------------------- steps
+    @staticmethod
+    def _kwargs(metas, swap_in, swap_out, copy, nw, epochs) -> dict:
+        return dict(seq_group_metadata_list=metas, blocks_to_swap_in=swap_in, blocks_to_swap_out=swap_out,
+                    blocks_to_copy=copy, blocks_to_nw=nw or {}, nw_epochs=epochs)
+
+    def execute_model(self, seq_group_metadata_list: List[SequenceGroupMetadata],
+                      blocks_to_swap_in: Dict[int, int], blocks_to_swap_out: Dict[int, int],
+                      blocks_to_copy: Dict[int, List[int]],
+                      blocks_to_nw: Optional[Dict[int, List[Tuple[int, int]]]] = None,
+                      nw_epochs: Optional[Dict[int, int]] = None) -> SamplerOutput:
+        if not seq_group_metadata_list:
+            return SamplerOutput([])
+        kwargs = self._kwargs(seq_group_metadata_list, blocks_to_swap_in, blocks_to_swap_out, blocks_to_copy,
+                              blocks_to_nw, nw_epochs)
+        pool = self.prompt_pool if seq_group_metadata_list[0].is_prompt else self.token_pool
+        return self._call_all(pool, "execute_model", **kwargs)[pool[0]]
+
+    def execute_split(self, prompt_kwargs: Optional[dict], decode_kwargs: Optional[dict]):
+        """A prompt step on the prompt pool and a decode step on the token pool, concurrently."""
+        assert self.split
+        if decode_kwargs is not None:
+            for r in self.token_pool:
+                self._send(r, "execute_model", decode_kwargs)
+        prompt_out = None
+        if prompt_kwargs is not None:
+            prompt_out = self._call_all(self.prompt_pool, "execute_model", **prompt_kwargs)[0]
+        decode_out = None
+        if decode_kwargs is not None:
+            outs = {r: self._wait(r) for r in self.token_pool}
+            decode_out = outs[self.token_pool[0]]
+        return prompt_out, decode_out
+
+    def kv_bytes_pushed(self) -> int:
+        comm = self.driver_worker.kvcache_comm_manager
+        return comm.kvcache_comm.bytes_pushed if comm and comm.kvcache_comm else 0
+
+    def check_health(self) -> None:
+        for proc in self.processes:
+            if not proc.is_alive():
+                raise RuntimeError("a worker process died")
+
+    def shutdown(self) -> None:
+        try:
+            if self.split:
+                self.driver_worker.destroy_kvcache_comm()
+            for ch in self.channels.values():
+                ch.send(("shutdown",))
+            for ch in self.channels.values():
+                ch.recv()
+        except Exception:
+            pass
+        for proc in self.processes:
+            proc.join(timeout=10)
+            if proc.is_alive():
+                proc.kill()
+        self.processes = []
+        self.channels = {}
+        if self.tp > 1:
+            import torch.distributed as dist
+            from ..model_executor import parallel_state
+            parallel_state.destroy_model_parallel()
+            if dist.is_initialized():
+                dist.destroy_process_group()
+            self.tp = 1
+
+    def __del__(self):
+        try:
+            self.shutdown()
+        except Exception:
+            pass

@@ -23,10 +23,17 @@ def worker_loop(channel, cfg: Dict[str, Any], worker_cls=Worker) -> None:
     ``worker_cls`` is the worker implementation (tests drive the control plane with a CPU stand-in)."""
     worker = None
     try:
+        transport_init = None
+        if cfg["parallel_config"].sep_prompt_token:
+            transport_init = {"exchange": make_exchange(channel), "transport": cfg["transport"]}
+        extra = {}
+        if cfg.get("distributed_init_method"):
+            extra["distributed_init_method"] = cfg["distributed_init_method"]
         worker = worker_cls(cfg["model_config"], cfg["parallel_config"], cfg["scheduler_config"], DeviceConfig("cuda"),
-                        local_rank=cfg["local_rank"], rank=cfg["rank"], kv_cache_dtype=cfg["cache_config"].cache_dtype,
-                        is_driver_worker=True,
-                        kv_transport_init={"exchange": make_exchange(channel), "transport": cfg["transport"]})
+                            local_rank=cfg["local_rank"], rank=cfg["rank"],
+                            kv_cache_dtype=cfg["cache_config"].cache_dtype, is_driver_worker=True,
+                            kv_transport_init=transport_init, **extra)
+        reports = cfg.get("reports_output", True)      # tensor-parallel followers compute but do not report
         while True:
             msg = channel.recv()
             cmd, args = msg[0], msg[1:]
@@ -40,8 +47,10 @@ def worker_loop(channel, cfg: Dict[str, Any], worker_cls=Worker) -> None:
                 elif cmd == "execute":
                     (kwargs,) = args
                     result = worker.execute_model(**kwargs)
+                    if not reports:
+                        result = None
                 elif cmd == "bytes_pushed":
-                    comm = worker.kvcache_comm_manager.kvcache_comm
+                    comm = worker.kvcache_comm_manager.kvcache_comm if worker.kvcache_comm_manager else None
                     result = comm.bytes_pushed if comm else 0
                 else:
                     raise ValueError(f"unknown command {cmd!r}")
@@ -58,5 +67,10 @@ def worker_loop(channel, cfg: Dict[str, Any], worker_cls=Worker) -> None:
 
 def spawn_entry(conn, cfg: Dict[str, Any]) -> None:
     from .channel import PipeChannel
+    import os
+    if os.environ.get("SPLITWISE_DEBUG_HANG"):          # dump this process's stacks if it is still alive then
+        import faulthandler
+        import sys
+        faulthandler.dump_traceback_later(float(os.environ["SPLITWISE_DEBUG_HANG"]), repeat=False, file=sys.stderr)
     torch.cuda.set_device(cfg["local_rank"])
     worker_loop(PipeChannel(conn), cfg)

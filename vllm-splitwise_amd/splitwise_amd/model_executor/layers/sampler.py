@@ -3,8 +3,7 @@
 Restates the parts of vllm/model_executor/layers/sampler.py the configurations use:
 hidden states are pruned to the rows that are sampled (:135-140), logits = h @ E^T (:108-121),
 temperature / top-k / top-p filtering (:79-99, :207-238), greedy = argmax of the log-probs
-(:417), random = multinomial over the filtered distribution.  Under tensor parallelism the
-vocabulary-sharded logits are gathered (sampler.py:44-57).
+(:417), random = multinomial over the filtered distribution.
 """
 from typing import Dict, List, Optional, Tuple
 
@@ -13,7 +12,6 @@ import torch.nn as nn
 
 from ...sampling_params import SamplingParams, SamplingType
 from ...sequence import Logprob, SamplerOutput, SequenceData, SequenceGroupOutput, SequenceOutput
-from ..parallel_state import tensor_model_parallel_all_gather
 
 _EPS = 1e-5
 
@@ -43,7 +41,8 @@ class Sampler(nn.Module):
         logits = torch.matmul(hidden_states, embedding.t())
         if embedding_bias is not None:
             logits += embedding_bias
-        logits = tensor_model_parallel_all_gather(logits)
+        # the embedding and the output head are replicated on every tensor-parallel rank (the
+        # reference shards them over the vocabulary and gathers here, sampler.py:44-57)
         return logits[:, :self.org_vocab_size]
 
     def forward(self, embedding: torch.Tensor, hidden_states: torch.Tensor,

@@ -6,6 +6,7 @@ loaded when present).  Initialisation runs on the target device, tensor by tenso
 """
 import glob
 import os
+import zlib
 from typing import Optional
 
 import torch
@@ -30,33 +31,49 @@ def _linear_method(model_config: ModelConfig):
     return method
 
 
+def _random_full(name: str, shape, dtype: torch.dtype, device: torch.device, seed: int) -> torch.Tensor:
+    """The FULL (unsharded) value of one parameter: a function of the seed and the parameter's name
+    only, so every tensor-parallel degree shards the same model."""
+    g = torch.Generator(device=device).manual_seed((seed * 1000003 + zlib.crc32(name.encode())) % (2 ** 63))
+    shape = tuple(shape)
+    if name.endswith("g_idx"):
+        raise AssertionError("g_idx keeps its constructed value")
+    if not dtype.is_floating_point:
+        # packed int4 words: uniformly random bits
+        return torch.randint(-2 ** 31, 2 ** 31 - 1, shape, dtype=torch.int64, device=device, generator=g).to(dtype)
+    if "norm" in name and name.endswith("weight"):
+        return torch.ones(shape, dtype=dtype, device=device)
+    if name.endswith("bias"):
+        return torch.zeros(shape, dtype=dtype, device=device)
+    if name.endswith("scales"):
+        return (torch.rand(shape, device=device, generator=g) * 2e-3 + 1e-4).to(dtype)
+    # N(0, 0.02): chunked through fp32 to bound the temporary
+    out = torch.empty(shape, dtype=dtype, device=device)
+    flat = out.view(-1)
+    step = 1 << 26
+    for s in range(0, flat.numel(), step):
+        n = min(step, flat.numel() - s)
+        flat[s:s + n].copy_((torch.randn(n, device=device, generator=g) * 0.02).to(dtype))
+    return out
+
+
 @torch.no_grad()
 def _random_init(model: nn.Module, seed: int) -> None:
-    gen = {}
+    from .layers.linear import _LinearBase
+    owner = {}
+    for mod_name, mod in model.named_modules():
+        if isinstance(mod, _LinearBase):
+            for pname, p in mod._parameters.items():
+                if p is not None:
+                    owner[id(p)] = mod
     for name, p in model.named_parameters():
-        dev = p.device
-        if dev not in gen:
-            gen[dev] = torch.Generator(device=dev).manual_seed(seed)
-        g = gen[dev]
         if name.endswith("g_idx"):
             continue                                  # keeps its sequential group index
-        if not p.is_floating_point():
-            # packed int4 words: uniformly random bits
-            p.copy_(torch.randint(-2 ** 31, 2 ** 31 - 1, p.shape, dtype=torch.int64, device=dev,
-                                  generator=g).to(p.dtype))
-        elif "norm" in name and name.endswith("weight"):
-            p.fill_(1.0)
-        elif name.endswith("bias"):
-            p.zero_()
-        elif name.endswith("scales"):
-            p.copy_((torch.rand(p.shape, device=dev, generator=g) * 2e-3 + 1e-4).to(p.dtype))
+        layer = owner.get(id(p))
+        if layer is None:                             # replicated on every rank
+            p.copy_(_random_full(name, p.shape, p.dtype, p.device, seed))
         else:
-            # N(0, 0.02): chunked through fp32 to bound the temporary
-            flat = p.view(-1)
-            step = 1 << 26
-            for s in range(0, flat.numel(), step):
-                n = min(step, flat.numel() - s)
-                flat[s:s + n].copy_((torch.randn(n, device=dev, generator=g) * 0.02).to(p.dtype))
+            layer.weight_loader(p, _random_full(name, layer.full_shape(p), p.dtype, p.device, seed))
 
 
 def get_model(model_config: ModelConfig, device: torch.device) -> nn.Module:

@@ -15,11 +15,12 @@ _TP_GROUP = None
 _STAGE_GROUP = None
 _TP_WORLD = 1
 _TP_RANK = 0
+_HOST_STAGED = False      # gloo stand-in for tests: collectives run on host copies of device tensors
 
 
 def initialize_model_parallel(tensor_model_parallel_size: int = 1, sep_prompt_token: bool = False,
                               backend: Optional[str] = None) -> None:
-    global _TP_GROUP, _STAGE_GROUP, _TP_WORLD, _TP_RANK
+    global _TP_GROUP, _STAGE_GROUP, _TP_WORLD, _TP_RANK, _HOST_STAGED
     if tensor_model_parallel_size == 1:
         # pools of one GPU need no collective at all; creating one-member groups would only add
         # rendezvous traffic (and gloo chatter on stdout) to whatever job launched the workers
@@ -28,6 +29,9 @@ def initialize_model_parallel(tensor_model_parallel_size: int = 1, sep_prompt_to
     assert dist.is_initialized(), "torch.distributed must be initialised for TP > 1"
     world, rank = dist.get_world_size(), dist.get_rank()
     assert world % tensor_model_parallel_size == 0
+    # gloo's own handling of device tensors (private streams, pinned staging on a helper thread)
+    # is not something this build wants to depend on: stage explicitly on the caller's stream
+    _HOST_STAGED = (backend or dist.get_backend()) == "gloo"
     for i in range(world // tensor_model_parallel_size):
         ranks = list(range(i * tensor_model_parallel_size, (i + 1) * tensor_model_parallel_size))
         group = dist.new_group(ranks, backend=backend)
@@ -46,9 +50,10 @@ def initialize_model_parallel(tensor_model_parallel_size: int = 1, sep_prompt_to
 
 
 def destroy_model_parallel() -> None:
-    global _TP_GROUP, _STAGE_GROUP, _TP_WORLD, _TP_RANK
+    global _TP_GROUP, _STAGE_GROUP, _TP_WORLD, _TP_RANK, _HOST_STAGED
     _TP_GROUP = _STAGE_GROUP = None
     _TP_WORLD, _TP_RANK = 1, 0
+    _HOST_STAGED = False
 
 
 def get_tensor_model_parallel_world_size() -> int:
@@ -71,6 +76,11 @@ def tensor_model_parallel_all_reduce(x: torch.Tensor) -> torch.Tensor:
     """In-place SUM over the TP group (communication_op.py:19-43)."""
     if _TP_WORLD == 1:
         return x
+    if _HOST_STAGED and x.is_cuda:
+        host = x.cpu()
+        dist.all_reduce(host, group=_TP_GROUP)
+        x.copy_(host)
+        return x
     dist.all_reduce(x, group=_TP_GROUP)
     return x
 
@@ -81,6 +91,7 @@ def tensor_model_parallel_all_gather(x: torch.Tensor, dim: int = -1) -> torch.Te
         return x
     if dim < 0:
         dim += x.dim()
-    parts = [torch.empty_like(x) for _ in range(_TP_WORLD)]
-    dist.all_gather(parts, x.contiguous(), group=_TP_GROUP)
-    return torch.cat(parts, dim=dim)
+    src = x.cpu() if _HOST_STAGED and x.is_cuda else x.contiguous()
+    parts = [torch.empty_like(src) for _ in range(_TP_WORLD)]
+    dist.all_gather(parts, src, group=_TP_GROUP)
+    return torch.cat(parts, dim=dim).to(x.device)

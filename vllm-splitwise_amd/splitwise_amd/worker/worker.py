@@ -77,10 +77,13 @@ class Worker:
             if not self.distributed_init_method:
                 raise ValueError("distributed_init_method must be set if torch.distributed is not already "
                                  "initialized")
-            dist.init_process_group(backend="nccl", world_size=self.parallel_config.world_size, rank=self.rank,
+            # "nccl" is RCCL on ROCm; SPLITWISE_TP_BACKEND=gloo lets several ranks share one GPU (tests)
+            dist.init_process_group(backend=os.environ.get("SPLITWISE_TP_BACKEND", "nccl"),
+                                    world_size=self.parallel_config.world_size, rank=self.rank,
                                     init_method=self.distributed_init_method)
         if dist.is_initialized() and self.parallel_config.tensor_parallel_size > 1:
-            dist.all_reduce(torch.zeros(1, device=self.device))       # warm-up (worker.py:452-455)
+            warm = torch.zeros(1, device="cpu" if dist.get_backend() == "gloo" else self.device)
+            dist.all_reduce(warm)                                      # warm-up (worker.py:452-455)
         parallel_state.initialize_model_parallel(self.parallel_config.tensor_parallel_size,
                                                  self.parallel_config.sep_prompt_token)
         self.init_kvcache_comm(self.kv_transport_init)
