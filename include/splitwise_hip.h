@@ -152,6 +152,11 @@ int sw_prefill_attention(void* out, const void* query, const void* key,
  * sw_ipc_*: export a device allocation to / map it from another process on this node
  * (HIP IPC; peer GPUs are reached over xGMI).  A handle is 64 opaque bytes.            */
 int sw_ipc_get_mem_handle(const void* dev_ptr, void* handle_out64);
+/* Base address and size of the device allocation that contains dev_ptr.  A handle always names a
+ * whole allocation: callers whose buffer is carved out of a larger one (a caching allocator's
+ * segment) export the base and send the buffer's offset beside the handle, as
+ * comm_utils.py:171-207 registers whole tensors by data_ptr and size.                        */
+int sw_mem_address_range(const void* dev_ptr, void** base_out, int64_t* size_out);
 int sw_ipc_open_mem_handle(const void* handle64, void** dev_ptr_out);
 int sw_ipc_close_mem_handle(void* dev_ptr);
 

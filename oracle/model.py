@@ -38,8 +38,20 @@ def _rope_neox(x, num_heads, positions, theta):
     return torch.cat((x1 * cos - x2 * sin, x2 * cos + x1 * sin), -1).reshape(n, num_heads * d)
 
 
-def llama_logits(sd: Dict[str, torch.Tensor], cfg: dict, tokens: List[int]) -> torch.Tensor:
+def _through_e5m2(t: torch.Tensor, act_dtype: torch.dtype) -> torch.Tensor:
+    """What a decode step reads back from an fp8-e5m2 cache: the 16-bit activation rounded once
+    more to e5m2 (csrc/cache_kernels.cu:201-214 writes, attention_kernels.cu:222-232 reads)."""
+    from . import fp8
+    return fp8.from_e5m2(fp8.to_e5m2(t.to(act_dtype)), torch.float32)
+
+
+def llama_logits(sd: Dict[str, torch.Tensor], cfg: dict, tokens: List[int], prompt_len: int = None,
+                 kv_cache_dtype: str = "auto", act_dtype: torch.dtype = torch.float16) -> torch.Tensor:
+    """``kv_cache_dtype="fp8_e5m2"``: positions from ``prompt_len`` on are decode steps and attend
+    to keys and values as the cache holds them (e5m2); prompt positions attend to the exact
+    ones, as the prompt step computes attention before anything is read back from the cache."""
     sd = {k: v.float() for k, v in sd.items()}
+    fp8_cache = kv_cache_dtype == "fp8_e5m2"
     h, kvh = cfg["num_attention_heads"], cfg.get("num_key_value_heads", cfg["num_attention_heads"])
     d = cfg["hidden_size"] // h
     eps = cfg.get("rms_norm_eps", 1e-6)
@@ -52,7 +64,11 @@ def llama_logits(sd: Dict[str, torch.Tensor], cfg: dict, tokens: List[int]) -> t
         q, k, v = qkv.split([h * d, kvh * d, kvh * d], -1)
         q = _rope_neox(q, h, pos, cfg.get("rope_theta", 10000.0))
         k = _rope_neox(k, kvh, pos, cfg.get("rope_theta", 10000.0))
-        x = x + _causal_attention(q, k, v, h, kvh) @ sd[p + "self_attn.o_proj.weight"].t()
+        a = _causal_attention(q, k, v, h, kvh)
+        if fp8_cache:
+            a_dec = _causal_attention(q, _through_e5m2(k, act_dtype), _through_e5m2(v, act_dtype), h, kvh)
+            a = torch.cat((a[:prompt_len], a_dec[prompt_len:]))
+        x = x + a @ sd[p + "self_attn.o_proj.weight"].t()
         y = _rms(x, sd[p + "post_attention_layernorm.weight"], eps)
         gu = y @ sd[p + "mlp.gate_up_proj.weight"].t()
         g, u = gu.chunk(2, -1)
@@ -81,5 +97,5 @@ def opt_logits(sd: Dict[str, torch.Tensor], cfg: dict, tokens: List[int]) -> tor
     return x @ sd["embed_tokens.weight"].t()
 
 
-def logits(architecture: str, sd, cfg, tokens):
-    return llama_logits(sd, cfg, tokens) if architecture == "llama" else opt_logits(sd, cfg, tokens)
+def logits(architecture: str, sd, cfg, tokens, **kv):
+    return llama_logits(sd, cfg, tokens, **kv) if architecture == "llama" else opt_logits(sd, cfg, tokens)

@@ -12,9 +12,9 @@ from oracle import model as omodel
 pytestmark = pytest.mark.gpu
 
 
-def _dense_state_dict(sd, quantization):
+def _dense_state_dict(sd, quantization, shuffled=True):
     """Replaces every int4 linear layer by the fp16 weight the CPU restatement reconstructs from
-    it (GPTQ weights have been shuffled in place by the first forward pass)."""
+    it (GPTQ weights have been shuffled in place by a model's first forward pass)."""
     from oracle import quant
     out = dict(sd)
     for key in sd:
@@ -23,7 +23,7 @@ def _dense_state_dict(sd, quantization):
         prefix = key[:-len("qweight")]
         qw, qz, sc = (sd[prefix + n].numpy() for n in ("qweight", "qzeros", "scales"))
         if quantization == "gptq":
-            w = quant.gptq_dequant(qw, qz, sc, None, use_exllama=True)
+            w = quant.gptq_dequant(qw, qz, sc, None, use_exllama=shuffled)
         else:
             w = quant.awq_dequantize(qw, sc, qz)
         out[prefix + "weight"] = torch.from_numpy(w.T.copy())          # [out, in] like a dense layer
@@ -131,6 +131,38 @@ def test_tensor_parallel_pools_match_cpu_model(split, monkeypatch):
         gen = out.outputs[0].token_ids
         assert len(gen) == 16
         ref = omodel.logits(cfg["architecture"], sd, cfg, prompt + gen)
+        for j, tok in enumerate(gen):
+            row = ref[len(prompt) + j - 1]
+            assert row[tok] >= row.max() - 3e-2, (j, tok, int(row.argmax()), float(row.max() - row[tok]))
+
+
+def test_int4_fp8_cache_split_pools_match_cpu_model(monkeypatch):
+    """The quantised configuration in miniature: GPTQ int4 weights, fp8-e5m2 KV cache, a prompt
+    pool and a token pool of two tensor-parallel ranks each.  Judged by the CPU model on the
+    reconstructed full fp16 weights, with keys and values of decode steps passed through e5m2."""
+    from splitwise_amd import LLM, SamplingParams
+    from splitwise_amd.config import ModelConfig
+    from splitwise_amd.model_executor.model_loader import get_model
+    monkeypatch.setenv("SPLITWISE_TP_BACKEND", "gloo")
+    random.seed(4)
+    llm = LLM("llama-tiny", quantization="gptq", kv_cache_dtype="fp8_e5m2", tensor_parallel_size=2,
+              sep_prompt_token=True, num_gpu_blocks_override=128, max_num_seqs=8, max_model_len=512, swap_space=0.01)
+    try:
+        vocab = llm.llm_engine.model_config.get_vocab_size()
+        prompts = [[random.randrange(vocab) for _ in range(n)] for n in (5, 33, 64, 17, 100, 1)]
+        outs = llm.generate(prompt_token_ids=prompts, sampling_params=SamplingParams(temperature=0.0, max_tokens=12))
+        cfg = llm.llm_engine.model_config.hf_config
+    finally:
+        llm.llm_engine.model_executor.shutdown()
+        del llm
+        torch.cuda.empty_cache()
+    full = get_model(ModelConfig("llama-tiny", quantization="gptq"), torch.device("cuda"))
+    sd = _dense_state_dict({k: v.detach().cpu() for k, v in full.state_dict().items()}, "gptq", shuffled=False)
+    for prompt, out in zip(prompts, outs):
+        gen = out.outputs[0].token_ids
+        assert len(gen) == 12
+        ref = omodel.logits(cfg["architecture"], sd, cfg, prompt + gen, prompt_len=len(prompt),
+                            kv_cache_dtype="fp8_e5m2", act_dtype=torch.float16)
         for j, tok in enumerate(gen):
             row = ref[len(prompt) + j - 1]
             assert row[tok] >= row.max() - 3e-2, (j, tok, int(row.argmax()), float(row.max() - row[tok]))

@@ -73,15 +73,18 @@ def _split_llm(transport, **kw):
                max_num_seqs=8, max_model_len=512, swap_space=0.01, **kw)
 
 
-@pytest.mark.parametrize("transport", ["kernel", "runtime"])
-def test_transport_self_test_between_two_processes(transport):
-    """set_gpucache / send_recv_kvcache_all / check_gpucache of the reference, both transports."""
+@pytest.mark.parametrize("transport,blocks,kv_dtype", [("kernel", 64, "auto"), ("runtime", 64, "auto"),
+                                                       ("kernel", 16, "fp8_e5m2"), ("runtime", 16, "fp8_e5m2")])
+def test_transport_self_test_between_two_processes(transport, blocks, kv_dtype):
+    """set_gpucache / send_recv_kvcache_all / check_gpucache of the reference, both transports.
+    The 16-block fp8 cache is 132 KiB: it lives inside a shared segment of the caching allocator,
+    at an offset from the start of the device allocation that the peer maps."""
     from splitwise_amd.engine.arg_utils import EngineArgs
     from splitwise_amd.executor.splitwise_executor import SplitwiseExecutor
-    args = EngineArgs(model="llama-tiny", sep_prompt_token=True, enforce_eager=True, num_gpu_blocks_override=64,
-                      max_num_seqs=4, max_model_len=256, swap_space=0.01)
+    args = EngineArgs(model="llama-tiny", sep_prompt_token=True, enforce_eager=True, num_gpu_blocks_override=blocks,
+                      max_num_seqs=4, max_model_len=256, swap_space=0.01, kv_cache_dtype=kv_dtype)
     mc, cc, pc, sc, dc = args.create_engine_configs()
-    ex = SplitwiseExecutor(mc, cc, pc, sc, dc, num_gpu_blocks_override=64, prompt_device=0, token_device=0,
+    ex = SplitwiseExecutor(mc, cc, pc, sc, dc, num_gpu_blocks_override=blocks, prompt_device=0, token_device=0,
                            transport=transport)
     try:
         ex._remote_call("set_gpucache")
@@ -91,7 +94,12 @@ def test_transport_self_test_between_two_processes(transport):
         ex._remote_wait()
         ex._remote_call("check_gpucache")          # raises in the token worker on a mismatch
         ex.driver_worker.check_gpucache()
-        assert ex.kv_bytes_pushed() == 2 * mc.hf_config["num_hidden_layers"] * 64 * 16 * 2 * 64 * 2
+        elt = 1 if kv_dtype == "fp8_e5m2" else 2
+        assert ex.kv_bytes_pushed() == 2 * mc.hf_config["num_hidden_layers"] * blocks * 16 * 2 * 64 * elt
+        slab = ex.driver_worker.cache_engine.gpu_slab
+        if blocks == 16:
+            from splitwise_amd import _C
+            assert _C.kv_ops.mem_address_range(slab.data_ptr())[1] > slab.numel()     # the case this test is for
     finally:
         ex.shutdown()
 

@@ -105,6 +105,17 @@ int sw_ipc_get_mem_handle(const void* dev_ptr, void* handle_out64) {
   return SW_OK;
 }
 
+int sw_mem_address_range(const void* dev_ptr, void** base_out, int64_t* size_out) {
+  using namespace sw;
+  SW_CHECK_ARG(dev_ptr && base_out && size_out, "mem_address_range: NULL argument");
+  hipDeviceptr_t base = nullptr;
+  size_t size = 0;
+  SW_CHECK_HIP(hipMemGetAddressRange(&base, &size, const_cast<void*>(dev_ptr)));
+  *base_out = base;
+  *size_out = (int64_t)size;
+  return SW_OK;
+}
+
 int sw_ipc_open_mem_handle(const void* handle64, void** dev_ptr_out) {
   using namespace sw;
   SW_CHECK_ARG(handle64 && dev_ptr_out, "ipc_open_mem_handle: NULL argument");

@@ -56,6 +56,7 @@ _SIGNATURES = {
                             _c_int, _c_i64, _c_i64, _c_int, _c_void_p],
     "sw_silu_and_mul": [_c_void_p, _c_void_p, _c_i64, _c_int, _c_i64, _c_int, _c_void_p],
     "sw_ipc_get_mem_handle": [_c_void_p, _c_void_p],
+    "sw_mem_address_range": [_c_void_p, ctypes.POINTER(_c_void_p), ctypes.POINTER(_c_i64)],
     "sw_ipc_open_mem_handle": [_c_void_p, ctypes.POINTER(_c_void_p)],
     "sw_ipc_close_mem_handle": [_c_void_p],
     "sw_kv_push": [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p],
@@ -394,6 +395,13 @@ def ipc_get_mem_handle(dev_ptr: int) -> bytes:
     return buf.raw
 
 
+def mem_address_range(dev_ptr: int):
+    """(base address, size in bytes) of the device allocation that contains ``dev_ptr``."""
+    base, size = _c_void_p(), _c_i64()
+    _check(load_library().sw_mem_address_range(dev_ptr, ctypes.byref(base), ctypes.byref(size)))
+    return base.value, size.value
+
+
 def ipc_open_mem_handle(handle: bytes) -> int:
     out = _c_void_p()
     _check(load_library().sw_ipc_open_mem_handle(ctypes.c_char_p(handle), ctypes.byref(out)))
@@ -577,6 +585,7 @@ cache_ops = SimpleNamespace(
 )
 kv_ops = SimpleNamespace(
     ipc_get_mem_handle=ipc_get_mem_handle,
+    mem_address_range=mem_address_range,
     ipc_open_mem_handle=ipc_open_mem_handle,
     ipc_close_mem_handle=ipc_close_mem_handle,
     kv_push=kv_push,

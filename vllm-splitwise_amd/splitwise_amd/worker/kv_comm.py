@@ -187,9 +187,13 @@ class KVCacheCommManager:
         if slab is None:
             raise RuntimeError("KV transport needs the cache allocated as one slab (CacheEngine(slab=True))")
         self._slab = slab
-        if _ipc_safe_size(slab.numel()) != slab.numel():
-            raise RuntimeError(f"cache slab of {slab.numel()} bytes cannot be mapped by a peer process on this "
-                               "runtime; allocate it through slab_layout()")
+        # an IPC handle names a whole device allocation; the slab may sit inside a larger one (a
+        # segment of torch's caching allocator), so the allocation is exported and the slab's offset
+        # in it travels beside the handle
+        alloc_base, alloc_bytes = _C.kv_ops.mem_address_range(slab.data_ptr())
+        if _ipc_safe_size(alloc_bytes) != alloc_bytes:
+            raise RuntimeError(f"the cache slab lives in a device allocation of {alloc_bytes} bytes, which a peer "
+                               "process cannot map on this runtime; allocate it through slab_layout()")
         device = slab.device
         block_bytes = k0[0].numel() * k0.element_size()
         base = slab.data_ptr()
@@ -201,7 +205,8 @@ class KVCacheCommManager:
         slab[flags_offset:].zero_()
         torch.cuda.synchronize(device)
         info = {"rank": self.rank, "nbytes": slab.numel(), "layer_offsets": layer_offsets,
-                "handle": _C.kv_ops.ipc_get_mem_handle(base), "pid_device": (torch.cuda.current_device(),)}
+                "handle": _C.kv_ops.ipc_get_mem_handle(alloc_base), "offset": base - alloc_base,
+                "pid_device": (torch.cuda.current_device(),)}
         peer = self.exchange(info)
         if peer["rank"] != self.corr_worker_rank:
             raise RuntimeError(f"KV transport paired rank {self.rank} with {peer['rank']}, expected "
@@ -210,9 +215,10 @@ class KVCacheCommManager:
             raise RuntimeError("prompt and token workers disagree on the cache layout")
         peer_base = 0
         if self.is_prompt_side:
-            peer_base = _bounded(lambda: _C.kv_ops.ipc_open_mem_handle(peer["handle"]), _IPC_OPEN_TIMEOUT_S,
-                                 "mapping the token worker's KV cache (hipIpcOpenMemHandle)")
-            self._peer_mapping = peer_base
+            mapped = _bounded(lambda: _C.kv_ops.ipc_open_mem_handle(peer["handle"]), _IPC_OPEN_TIMEOUT_S,
+                              "mapping the token worker's KV cache (hipIpcOpenMemHandle)")
+            self._peer_mapping = mapped
+            peer_base = mapped + peer["offset"]
         comm = KVCacheCommunicator(block_bytes, layer_offsets, base, peer_base, flags_offset, self.transport, device)
         if self.transport == "runtime":
             comm.local_bytes = slab

@@ -78,9 +78,12 @@ class Worker:
                 raise ValueError("distributed_init_method must be set if torch.distributed is not already "
                                  "initialized")
             # "nccl" is RCCL on ROCm; SPLITWISE_TP_BACKEND=gloo lets several ranks share one GPU (tests)
+            import datetime
+            # bounded: a rank that died while starting must not leave the others waiting for half an hour
+            timeout = datetime.timedelta(seconds=float(os.environ.get("SPLITWISE_DIST_TIMEOUT_S", "600")))
             dist.init_process_group(backend=os.environ.get("SPLITWISE_TP_BACKEND", "nccl"),
                                     world_size=self.parallel_config.world_size, rank=self.rank,
-                                    init_method=self.distributed_init_method)
+                                    init_method=self.distributed_init_method, timeout=timeout)
         if dist.is_initialized() and self.parallel_config.tensor_parallel_size > 1:
             warm = torch.zeros(1, device="cpu" if dist.get_backend() == "gloo" else self.device)
             dist.all_reduce(warm)                                      # warm-up (worker.py:452-455)
