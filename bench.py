@@ -57,6 +57,8 @@ def parse_args():
     ap.add_argument("--prefill-batch-tokens", type=int, default=2300,
                     help="hold waiting prompts until this many tokens have gathered (0 = admit at once)")
     ap.add_argument("--prefill-max-wait", type=float, default=0.08, help="... or the oldest has waited this long (s)")
+    ap.add_argument("--no-pipeline-steps", action="store_true",
+                    help="wait for a step's tokens before scheduling the next step (the reference's loop)")
     ap.add_argument("--enforce-eager", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -242,7 +244,8 @@ def main():
         model=args.model, max_num_seqs=conc, max_model_len=2048, max_num_batched_tokens=args.max_num_batched_tokens,
         num_gpu_blocks_override=int(conc * seq_blocks * 1.25) + 64, swap_space=0.25,
         enforce_eager=args.enforce_eager, max_context_len_to_capture=1024,
-        prefill_batch_tokens=args.prefill_batch_tokens, prefill_max_wait=args.prefill_max_wait))
+        prefill_batch_tokens=args.prefill_batch_tokens, prefill_max_wait=args.prefill_max_wait,
+        pipeline_steps=not args.no_pipeline_steps))
     loop = ClosedLoop(engine, conc, args.prompt_len, args.decode_len, seed=0)
 
     # sample decode batches of the timed region for the roofline measurement (references only)
@@ -291,7 +294,7 @@ def main():
                                f"SLO TTFT<={SLO_TTFT}s TPOT<={SLO_TPOT}s",
                    "concurrency": conc, "prompt_len": args.prompt_len, "decode_len": args.decode_len,
                    "prefill_batch_tokens": args.prefill_batch_tokens, "prefill_max_wait_s": args.prefill_max_wait,
-                   "hip_graphs": not args.enforce_eager},
+                   "hip_graphs": not args.enforce_eager, "pipeline_steps": not args.no_pipeline_steps},
         "throughput_tok_s": round(total / elapsed, 2),
         "slo_attainment": round(met / max(seen, 1), 4),
         "prompt_steps": loop.step_kinds[True][0],

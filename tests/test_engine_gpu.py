@@ -166,3 +166,32 @@ def test_int4_fp8_cache_split_pools_match_cpu_model(monkeypatch):
         for j, tok in enumerate(gen):
             row = ref[len(prompt) + j - 1]
             assert row[tok] >= row.max() - 3e-2, (j, tok, int(row.argmax()), float(row.max() - row[tok]))
+
+
+@pytest.mark.parametrize("enforce_eager,blocks", [(True, 256), (False, 256), (False, 24)])
+def test_pipelined_steps_generate_the_same_tokens(enforce_eager, blocks):
+    """Step n+1 is launched before step n's tokens reach the host (they are read on the device):
+    greedy and seeded random requests must come out token for token as from the plain loop; with
+    24 blocks sequences are preempted and recomputed on the way."""
+    from splitwise_amd import LLM, SamplingParams
+    random.seed(5)
+    prompts = [[random.randrange(512) for _ in range(n)] for n in (5, 33, 64, 17, 100, 1, 16, 48)]
+    params = [SamplingParams(temperature=0.0, max_tokens=20 + i) for i in range(6)]
+    params += [SamplingParams(temperature=0.8, top_p=0.9, seed=11, max_tokens=20),
+               SamplingParams(temperature=1.0, top_k=20, seed=12, max_tokens=25, logprobs=1)]
+    results = []
+    for pipeline in (False, True):
+        llm = LLM("llama-tiny", enforce_eager=enforce_eager, num_gpu_blocks_override=blocks, max_num_seqs=8,
+                  max_model_len=256, swap_space=0.01, pipeline_steps=pipeline)
+        assert llm.llm_engine.pipeline_steps == pipeline
+        for i, (prompt, sp) in enumerate(zip(prompts, params)):
+            llm.llm_engine.add_request(str(i), None, sp, prompt_token_ids=prompt)
+        outs = llm._run_engine()
+        results.append([(o.outputs[0].token_ids, o.outputs[0].finish_reason) for o in outs])
+        if blocks == 24:
+            assert llm.llm_engine.scheduler.num_preemptions > 0
+        lps = [o.outputs[0].cumulative_logprob for o in outs]
+        assert lps[-1] < 0.0
+        del llm
+        torch.cuda.empty_cache()
+    assert results[0] == results[1]

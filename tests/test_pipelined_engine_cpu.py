@@ -1,0 +1,143 @@
+"""Pipelined engine steps on CPU: the real engine and scheduler over a stand-in executor whose
+deferred samples behave like the device's (a step's token is a function of everything before it,
+and becomes known to the host one engine call later).  The pipelined loop must produce exactly
+the outputs of the plain loop, including under preemption, stop tokens and aborts."""
+import pytest
+
+import conftest  # noqa: F401
+from split_fakes import VOCAB, next_token
+from splitwise_amd import EngineArgs, LLMEngine, SamplingParams
+from splitwise_amd.executor.executor_base import ExecutorBase
+from splitwise_amd.sequence import (PLACEHOLDER_TOKEN_ID, Logprob, SamplerOutput, SequenceGroupOutput,
+                                    SequenceOutput)
+
+
+def _sample(metas) -> SamplerOutput:
+    outs = []
+    for meta in metas:
+        (seq_id, data), = meta.seq_data.items()
+        ids = data.get_token_ids()
+        if ids[-1] == PLACEHOLDER_TOKEN_ID:        # this step's own placeholder: the step ran before it existed
+            ids = ids[:-1]
+        assert PLACEHOLDER_TOKEN_ID not in ids
+        tok = next_token(ids)
+        outs.append(SequenceGroupOutput([SequenceOutput(seq_id, tok, {tok: Logprob(-0.5)})]))
+    return SamplerOutput(outs)
+
+
+class _Deferred:
+    def __init__(self, metas):
+        self.metas = metas
+
+    def resolve(self) -> SamplerOutput:
+        return _sample(self.metas)
+
+
+class FakeExecutor(ExecutorBase):
+    supports_deferred_samples = True
+
+    def __init__(self):
+        self.steps = 0
+        self.prompt_tokens_seen = []
+
+    def execute_model(self, seq_group_metadata_list, blocks_to_swap_in, blocks_to_swap_out, blocks_to_copy,
+                      blocks_to_nw=None, defer=False):
+        self.steps += 1
+        for meta in seq_group_metadata_list:
+            (seq_id, data), = meta.seq_data.items()
+            ids = data.get_token_ids()
+            if meta.is_prompt:
+                assert PLACEHOLDER_TOKEN_ID not in ids          # a prompt step needs every token on the host
+            else:
+                assert PLACEHOLDER_TOKEN_ID not in ids[:-1]     # at most the last token is still on the device
+        return _Deferred(seq_group_metadata_list) if defer else _sample(seq_group_metadata_list)
+
+    def check_health(self) -> None:
+        pass
+
+
+def _engine(pipeline: bool, blocks: int = 64, max_num_seqs: int = 4) -> LLMEngine:
+    args = EngineArgs(model="llama-tiny", max_num_seqs=max_num_seqs, max_model_len=256, max_num_batched_tokens=256,
+                      swap_space=0.001, pipeline_steps=pipeline)
+    mc, cc, pc, sc, dc = args.create_engine_configs()
+    cc.num_gpu_blocks, cc.num_cpu_blocks = blocks, 8
+    return LLMEngine(mc, cc, pc, sc, dc, executor=FakeExecutor())
+
+
+def _run(engine, requests, late=None, abort_at=None):
+    """-> {request id: (token ids, finish reason, cumulative logprob, number of outputs seen)}"""
+    for rid, (prompt, params) in requests.items():
+        engine.add_request(rid, None, params, prompt_token_ids=prompt)
+    final, seen = {}, {}
+    calls = 0
+    while engine.has_unfinished_requests():
+        calls += 1
+        assert calls < 5000
+        if late and calls in late:
+            rid, (prompt, params) = late[calls]
+            engine.add_request(rid, None, params, prompt_token_ids=prompt)
+        if abort_at and calls == abort_at[0]:
+            engine.abort_request(abort_at[1])
+        for out in engine.step():
+            seen[out.request_id] = seen.get(out.request_id, 0) + 1
+            c = out.outputs[0]
+            assert PLACEHOLDER_TOKEN_ID not in c.token_ids
+            if out.finished:
+                final[out.request_id] = (list(c.token_ids), c.finish_reason, round(c.cumulative_logprob, 6),
+                                         seen[out.request_id])
+    return final
+
+
+def _requests(n, max_tokens, **kw):
+    return {f"r{i}": ([(5 * i + j) % VOCAB for j in range(3 + 7 * i)],
+                      SamplingParams(temperature=0.0, max_tokens=max_tokens + i, ignore_eos=True, **kw))
+            for i in range(n)}
+
+
+def test_pipelined_outputs_equal_plain_outputs():
+    plain = _run(_engine(False), _requests(7, 9))
+    piped = _run(_engine(True), _requests(7, 9))
+    assert piped == plain
+    assert all(len(v[0]) == 9 + i and v[1] == "length" and v[3] == 9 + i for i, v in
+               ((int(k[1:]), v) for k, v in piped.items()))
+
+
+def test_pipelined_with_preemption_by_recomputation():
+    # 10 blocks of 16 tokens for four sequences that grow to ~60 tokens each: some are recomputed
+    reqs = {f"r{i}": ([(3 * i + j) % VOCAB for j in range(20 + i)],
+                      SamplingParams(temperature=0.0, max_tokens=40, ignore_eos=True)) for i in range(4)}
+    e_plain, e_piped = _engine(False, blocks=10), _engine(True, blocks=10)
+    plain, piped = _run(e_plain, reqs), _run(e_piped, reqs)
+    assert e_plain.scheduler.num_preemptions > 0 and e_piped.scheduler.num_preemptions > 0
+    assert {k: v[:3] for k, v in piped.items()} == {k: v[:3] for k, v in plain.items()}
+    assert e_piped.scheduler.block_manager.get_num_free_gpu_blocks() == 10
+
+
+def test_pipelined_stop_token_drops_the_speculative_step():
+    base = _run(_engine(False), _requests(3, 30))
+    stops = {}
+    for rid, (toks, _, _, _) in base.items():
+        stops[rid] = toks[7]                     # a token each request is known to produce
+    def with_stops():
+        reqs = _requests(3, 30)
+        return {rid: (p, SamplingParams(temperature=0.0, max_tokens=sp.max_tokens, ignore_eos=True,
+                                        stop_token_ids=[stops[rid]])) for rid, (p, sp) in reqs.items()}
+    e_piped = _engine(True)
+    plain, piped = _run(_engine(False), with_stops()), _run(e_piped, with_stops())
+    assert piped == plain
+    assert all(v[1] == "stop" and v[0][-1] == stops[k] for k, v in piped.items())
+    assert e_piped.scheduler.block_manager.get_num_free_gpu_blocks() == 64
+
+
+def test_pipelined_late_arrivals_and_abort():
+    late = {4: ("late0", ([9, 8, 7, 6], SamplingParams(temperature=0.0, max_tokens=6, ignore_eos=True))),
+            9: ("late1", ([1] * 40, SamplingParams(temperature=0.0, max_tokens=3, ignore_eos=True)))}
+    plain = _run(_engine(False), _requests(3, 12), late=late)
+    piped = _run(_engine(True), _requests(3, 12), late=late)
+    assert {k: v[:3] for k, v in piped.items()} == {k: v[:3] for k, v in plain.items()}
+    engine = _engine(True)
+    out = _run(engine, _requests(3, 12), abort_at=(5, "r1"))
+    assert "r1" not in out and set(out) == {"r0", "r2"}
+    assert out["r0"][:3] == plain["r0"][:3] and out["r2"][:3] == plain["r2"][:3]
+    assert engine.scheduler.block_manager.get_num_free_gpu_blocks() == 64
+    assert not engine.has_unfinished_requests()

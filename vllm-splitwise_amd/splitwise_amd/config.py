@@ -171,9 +171,11 @@ class SchedulerConfig:
     """vllm/config.py:474-520."""
 
     def __init__(self, max_num_batched_tokens: Optional[int], max_num_seqs: int, max_model_len: int,
-                 max_paddings: int = 256, prefill_batch_tokens: int = 0, prefill_max_wait: float = 0.1) -> None:
+                 max_paddings: int = 256, prefill_batch_tokens: int = 0, prefill_max_wait: float = 0.1,
+                 pipeline_steps: bool = False) -> None:
         # prefill batching (0 = off: prompts are admitted as soon as they fit, as in the reference)
         self.prefill_batch_tokens = prefill_batch_tokens
+        self.pipeline_steps = pipeline_steps
         self.prefill_max_wait = prefill_max_wait
         if max_num_batched_tokens is None:
             max_num_batched_tokens = max(max_model_len, 2048)

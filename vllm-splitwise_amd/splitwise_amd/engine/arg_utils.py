@@ -28,6 +28,7 @@ class EngineArgs:
     max_paddings: int = 256
     prefill_batch_tokens: int = 0
     prefill_max_wait: float = 0.1
+    pipeline_steps: bool = False     # launch step n+1 before step n's tokens reach the host (co-located engine)
     quantization: Optional[str] = None
     enforce_eager: bool = False
     max_context_len_to_capture: Optional[int] = None
@@ -62,5 +63,6 @@ class EngineArgs:
         model_config.verify_with_parallel_config(parallel_config)
         scheduler_config = SchedulerConfig(self.max_num_batched_tokens, self.max_num_seqs,
                                            model_config.max_model_len, self.max_paddings,
-                                           self.prefill_batch_tokens, self.prefill_max_wait)
+                                           self.prefill_batch_tokens, self.prefill_max_wait,
+                                           self.pipeline_steps)
         return model_config, cache_config, parallel_config, scheduler_config, DeviceConfig(self.device)

@@ -50,6 +50,11 @@ class LLMEngine:
         # split pools: run a prompt step and a decode step concurrently when the executor can
         self.overlap_pools = parallel_config.sep_prompt_token and hasattr(self.model_executor, "execute_split")
         self._slot_epoch: Dict[int, int] = {}
+        # pipelined steps (co-located engine only): step n+1 is scheduled and launched while step n
+        # still runs; a step's tokens are appended, and its outputs returned, one call later
+        self.pipeline_steps = (getattr(scheduler_config, "pipeline_steps", False) and not self.overlap_pools
+                               and getattr(self.model_executor, "supports_deferred_samples", False))
+        self._inflight = None           # (pending samples, scheduler outputs, [(group, sequence)])
 
     @classmethod
     def from_engine_args(cls, engine_args: EngineArgs, **kwargs) -> "LLMEngine":
@@ -79,7 +84,7 @@ class LLMEngine:
         return self.scheduler.get_num_unfinished_seq_groups()
 
     def has_unfinished_requests(self) -> bool:
-        return self.scheduler.has_unfinished_seqs()
+        return self.scheduler.has_unfinished_seqs() or self._inflight is not None
 
     # --------------------------------------------------------------------- step
     def _check_stop(self, seq: Sequence, params: SamplingParams) -> None:
@@ -144,11 +149,78 @@ class LLMEngine:
             self.scheduler.prompt_step_done([m.request_id for m in metas_p])
         return outputs
 
+    # ----------------------------------------------------------- pipelined steps
+    def _finished_by_length(self, seq: Sequence, params: SamplingParams) -> bool:
+        """The stop rules of ``_check_stop`` that depend on lengths only: they are known as soon as
+        a token has been sampled, before its value is."""
+        return (seq.get_len() > self.scheduler_config.max_model_len
+                or (params.max_tokens is not None and seq.get_output_len() == params.max_tokens))
+
+    def _resolve_inflight(self) -> List[RequestOutput]:
+        pending, scheduler_outputs, pairs = self._inflight
+        self._inflight = None
+        output = pending.resolve()
+        now = time.time()
+        reported: List[SequenceGroup] = []
+        for (group, seq), out in zip(pairs, output):
+            if not seq.has_placeholder():
+                continue        # ended (stop token, abort) before this step's token was accounted for: dropped
+            sample = out.samples[0]
+            seq.fill_placeholder(sample.output_token, sample.logprobs)
+            if seq.status == SequenceStatus.FINISHED_ABORTED:
+                continue
+            if self.tokenizer is not None:
+                seq.output_text = self.tokenizer.decode(seq.get_output_token_ids())
+            if seq.is_finished():
+                # ended by length when the step was launched; a stop token takes precedence as in _check_stop
+                if sample.output_token in group.sampling_params.stop_token_ids:
+                    seq.status = SequenceStatus.FINISHED_STOPPED
+            else:
+                self._check_stop(seq, group.sampling_params)
+                if seq.is_finished():
+                    self.scheduler.free_seq(seq)
+                    if group in self.scheduler.waiting:      # preempted for recomputation in the meantime
+                        self.scheduler.waiting.remove(group)
+            group.maybe_set_first_token_time(now)
+            reported.append(group)
+        self.scheduler.free_finished_seq_groups()
+        if self.stat_logger is not None:
+            self.stat_logger.log(self._get_stats(scheduler_outputs, reported, now))
+        return [RequestOutput.from_seq_group(g) for g in reported]
+
+    def _step_pipelined(self) -> List[RequestOutput]:
+        metas, scheduler_outputs = self.scheduler.schedule()
+        launched = None
+        if not scheduler_outputs.is_empty():
+            pairs = [(g, g.get_seqs(status=SequenceStatus.RUNNING)[0])
+                     for g in scheduler_outputs.scheduled_seq_groups]
+            pending = self.model_executor.execute_model(
+                metas, scheduler_outputs.blocks_to_swap_in, scheduler_outputs.blocks_to_swap_out,
+                scheduler_outputs.blocks_to_copy, scheduler_outputs.blocks_to_nw, defer=True)
+            launched = (pending, scheduler_outputs, pairs)
+        # the previous step has finished by now (or does so while the new one runs)
+        outputs = self._resolve_inflight() if self._inflight is not None else []
+        if launched is not None:
+            for group, seq in launched[2]:
+                if seq.is_finished():
+                    continue        # a stop token of the previous step ended it; this step's sample is dropped
+                seq.append_placeholder()
+                if self._finished_by_length(seq, group.sampling_params):
+                    # device work is stream-ordered, so the blocks can be handed out again at once
+                    seq.status = SequenceStatus.FINISHED_LENGTH_CAPPED
+                    self.scheduler.free_seq(seq)
+            self.scheduler.free_finished_seq_groups()
+            self._inflight = launched
+        outputs += [RequestOutput.from_seq_group(g) for g in scheduler_outputs.ignored_seq_groups]
+        return outputs
+
     def step(self) -> List[RequestOutput]:
         """One scheduling decision, one model step on the executor, outputs appended
         (vllm/engine/llm_engine.py:571-633)."""
         if self.overlap_pools:
             return self._step_split()
+        if self.pipeline_steps:
+            return self._step_pipelined()
         metas, scheduler_outputs = self.scheduler.schedule()
         if not scheduler_outputs.is_empty():
             output = self.model_executor.execute_model(

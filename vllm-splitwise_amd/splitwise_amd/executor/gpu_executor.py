@@ -54,9 +54,13 @@ class GPUExecutor(ExecutorBase):
     def execute_model(self, seq_group_metadata_list: List[SequenceGroupMetadata],
                       blocks_to_swap_in: Dict[int, int], blocks_to_swap_out: Dict[int, int],
                       blocks_to_copy: Dict[int, List[int]],
-                      blocks_to_nw: Optional[Dict[int, List[Tuple[int, int]]]] = None) -> SamplerOutput:
+                      blocks_to_nw: Optional[Dict[int, List[Tuple[int, int]]]] = None, defer: bool = False):
+        """``defer=True`` returns at once with the step's samples still on the device (an object with
+        ``resolve() -> SamplerOutput``); the engine's pipelined step loop is its only caller."""
         return self.driver_worker.execute_model(seq_group_metadata_list, blocks_to_swap_in, blocks_to_swap_out,
-                                                blocks_to_copy, blocks_to_nw or {})
+                                                blocks_to_copy, blocks_to_nw or {}, defer=defer)
+
+    supports_deferred_samples = True
 
     def check_health(self) -> None:
         return

@@ -21,13 +21,67 @@ class SamplingMetadata:
 
     def __init__(self, seq_groups: Optional[List[Tuple[List[int], SamplingParams]]],
                  seq_data: Optional[Dict[int, SequenceData]], prompt_lens: Optional[List[int]],
-                 selected_token_indices: torch.Tensor, generators=None, perform_sampling: bool = True) -> None:
+                 selected_token_indices: torch.Tensor, generators=None, perform_sampling: bool = True,
+                 defer: bool = False) -> None:
         self.seq_groups = seq_groups
         self.seq_data = seq_data
         self.prompt_lens = prompt_lens
         self.selected_token_indices = selected_token_indices
         self.generators = generators
         self.perform_sampling = perform_sampling
+        self.defer = defer          # leave the sampled tokens on the device; the caller resolves them later
+
+
+def _host_to_device(values, dtype: torch.dtype, device: torch.device) -> torch.Tensor:
+    """A small per-row parameter vector, copied without making the host wait for the stream."""
+    t = torch.tensor(values, dtype=dtype)
+    if device.type == "cuda":
+        return t.pin_memory().to(device, non_blocking=True)
+    return t.to(device)
+
+
+def _build_output(seq_groups, ids: List[int], chosen_lp: Optional[List[float]]) -> SamplerOutput:
+    outputs: List[SequenceGroupOutput] = []
+    row = 0
+    for seq_ids, _ in seq_groups:
+        samples = []
+        for seq_id in seq_ids:
+            lp = 0.0 if chosen_lp is None else chosen_lp[row]
+            samples.append(SequenceOutput(seq_id, ids[row], {ids[row]: Logprob(lp)}))
+            row += 1
+        outputs.append(SequenceGroupOutput(samples, None))
+    return SamplerOutput(outputs=outputs)
+
+
+class PendingSamples:
+    """The sampled tokens of a step that is still running: ``next_ids`` stays on the device (the
+    next step reads its input tokens from it), a copy is on its way to pinned host memory, and
+    ``resolve`` waits for that copy only."""
+
+    def __init__(self, seq_groups, next_ids: torch.Tensor, chosen_lp: Optional[torch.Tensor]) -> None:
+        self.seq_groups = seq_groups
+        self.next_ids = next_ids
+        self.row_of: Dict[int, int] = {}
+        for seq_ids, _ in seq_groups:
+            for seq_id in seq_ids:
+                self.row_of[seq_id] = len(self.row_of)
+        self.event = None
+        if next_ids.is_cuda:
+            self._ids = torch.empty(next_ids.shape, dtype=next_ids.dtype, pin_memory=True)
+            self._ids.copy_(next_ids, non_blocking=True)
+            self._lp = None
+            if chosen_lp is not None:
+                self._lp = torch.empty(chosen_lp.shape, dtype=chosen_lp.dtype, pin_memory=True)
+                self._lp.copy_(chosen_lp, non_blocking=True)
+            self.event = torch.cuda.Event()
+            self.event.record()
+        else:
+            self._ids, self._lp = next_ids, chosen_lp
+
+    def resolve(self) -> SamplerOutput:
+        if self.event is not None:
+            self.event.synchronize()
+        return _build_output(self.seq_groups, self._ids.tolist(), None if self._lp is None else self._lp.tolist())
 
 
 class Sampler(nn.Module):
@@ -83,15 +137,14 @@ class Sampler(nn.Module):
             next_ids = torch.argmax(logits, dim=-1)
             chosen_lp = None
         else:
-            temps = torch.tensor([p.temperature if p.temperature >= _EPS else 1.0 for p in rows],
-                                 dtype=torch.float32, device=logits.device)
-            if not torch.all(temps == 1.0):
-                logits = logits / temps.unsqueeze(1)
+            temps = [p.temperature if p.temperature >= _EPS else 1.0 for p in rows]
+            if any(t != 1.0 for t in temps):
+                logits = logits / _host_to_device(temps, torch.float32, logits.device).unsqueeze(1)
             vocab = logits.shape[1]
             if any(p.top_p < 1.0 - _EPS or (p.top_k != -1 and p.top_k != vocab) for p in rows):
-                top_ps = torch.tensor([p.top_p for p in rows], dtype=torch.float32, device=logits.device)
-                top_ks = torch.tensor([vocab if p.top_k == -1 else min(p.top_k, vocab) for p in rows],
-                                      dtype=torch.int32, device=logits.device)
+                top_ps = _host_to_device([p.top_p for p in rows], torch.float32, logits.device)
+                top_ks = _host_to_device([vocab if p.top_k == -1 else min(p.top_k, vocab) for p in rows],
+                                         torch.int32, logits.device)
                 logits = self._apply_top_k_top_p(logits, top_ps, top_ks)
             probs = torch.softmax(logits, dim=-1)
             logprobs = torch.log_softmax(logits, dim=-1)
@@ -103,18 +156,11 @@ class Sampler(nn.Module):
                 # rows of seeded requests redraw from their own generator (sampler.py:370-383)
                 for row_idx, g in (md.generators or {}).items():
                     random_ids[row_idx] = torch.multinomial(probs[row_idx], 1, generator=g)[0]
-                is_greedy = torch.tensor([p.sampling_type == SamplingType.GREEDY for p in rows],
-                                         device=logits.device)
+                is_greedy = _host_to_device([p.sampling_type == SamplingType.GREEDY for p in rows], torch.bool,
+                                            logits.device)
                 next_ids = torch.where(is_greedy, greedy_ids, random_ids)
-            chosen_lp = logprobs.gather(1, next_ids.unsqueeze(1)).squeeze(1).tolist()
-        ids = next_ids.tolist()                            # the one device -> host sync of the step
-        outputs: List[SequenceGroupOutput] = []
-        row = 0
-        for seq_ids, params in md.seq_groups:
-            samples = []
-            for seq_id in seq_ids:
-                lp = 0.0 if chosen_lp is None else chosen_lp[row]
-                samples.append(SequenceOutput(seq_id, ids[row], {ids[row]: Logprob(lp)}))
-                row += 1
-            outputs.append(SequenceGroupOutput(samples, None))
-        return SamplerOutput(outputs=outputs)
+            chosen_lp = logprobs.gather(1, next_ids.unsqueeze(1)).squeeze(1)
+        if md.defer:
+            return PendingSamples(md.seq_groups, next_ids, chosen_lp)
+        # the one device -> host sync of the step
+        return _build_output(md.seq_groups, next_ids.tolist(), None if chosen_lp is None else chosen_lp.tolist())

@@ -54,6 +54,11 @@ class RequestMetrics:
     finished_time: Optional[float] = None
 
 
+# Stands for a token that has been sampled on the device but has not reached the host yet
+# (pipelined engine steps): it takes the token's place in the sequence until the value arrives.
+PLACEHOLDER_TOKEN_ID = -1
+
+
 class SequenceData:
     def __init__(self, prompt_token_ids: List[int], output_token_ids: Optional[List[int]] = None) -> None:
         self.prompt_token_ids = prompt_token_ids
@@ -108,6 +113,20 @@ class Sequence:
         assert token_id in logprobs
         self.output_logprobs.append(logprobs)
         self.data.append_token_id(token_id, logprobs[token_id].logprob)
+
+    def append_placeholder(self) -> None:
+        self.output_logprobs.append({})
+        self.data.output_token_ids.append(PLACEHOLDER_TOKEN_ID)
+
+    def has_placeholder(self) -> bool:
+        out = self.data.output_token_ids
+        return bool(out) and out[-1] == PLACEHOLDER_TOKEN_ID
+
+    def fill_placeholder(self, token_id: int, logprobs: Dict[int, Logprob]) -> None:
+        assert self.has_placeholder() and token_id in logprobs
+        self.data.output_token_ids[-1] = token_id
+        self.output_logprobs[-1] = logprobs
+        self.data.cumulative_logprob += logprobs[token_id].logprob
 
     def get_len(self) -> int:
         return self.data.get_len()

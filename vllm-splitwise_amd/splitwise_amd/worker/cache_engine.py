@@ -81,6 +81,8 @@ class CacheEngine:
         return cache
 
     def _swap(self, src: List[KVCache], dst: List[KVCache], src_to_dst: Dict[int, int]) -> None:
+        # the blocks may still be written by kernels queued on the compute stream
+        self.cache_stream.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(self.cache_stream):
             for layer in range(self.num_layers):
                 _C.cache_ops.swap_blocks(src[layer][0], dst[layer][0], src_to_dst)

@@ -25,10 +25,10 @@ import torch
 
 from ..config import DeviceConfig, ModelConfig, ParallelConfig, SchedulerConfig
 from ..model_executor.input_metadata import InputMetadata
-from ..model_executor.layers.sampler import SamplingMetadata
+from ..model_executor.layers.sampler import PendingSamples, SamplingMetadata
 from ..model_executor.model_loader import get_model
 from ..sampling_params import SamplingParams
-from ..sequence import SamplerOutput, SequenceData, SequenceGroupMetadata
+from ..sequence import PLACEHOLDER_TOKEN_ID, SamplerOutput, SequenceData, SequenceGroupMetadata
 
 _PAD_SLOT_ID = -1
 _PROMPT_ROW_ALIGN = 16
@@ -70,6 +70,8 @@ class ModelRunner:
         self.graph_memory_pool = None
         self.max_context_len_to_capture = model_config.max_context_len_to_capture if model_config else 0
         self.enforce_eager = model_config.enforce_eager if model_config is not None else True
+        # samples of the previous step that were left on the device (pipelined engine steps)
+        self.pending: Optional[PendingSamples] = None
 
     # ------------------------------------------------------------------ set-up
     def load_model(self) -> None:
@@ -165,13 +167,24 @@ class ModelRunner:
         slots: List[int] = []
         context_lens: List[int] = []
         tables: List[List[int]] = []
+        # row of the previous step's device-resident samples that holds a sequence's last token when
+        # the host does not know it yet; -1 where the host's value is the one to use
+        from_pending: List[int] = []
         bs = self.block_size
         for meta in metas:
             assert not meta.is_prompt
             for seq_id, data in meta.seq_data.items():
                 seq_len = data.get_len()
                 pos = seq_len - 1
-                tokens.append(data.get_last_token_id())
+                last = data.get_last_token_id()
+                if last == PLACEHOLDER_TOKEN_ID:
+                    if self.pending is None or seq_id not in self.pending.row_of:
+                        raise RuntimeError(f"sequence {seq_id} waits for a token no earlier step left on the device")
+                    from_pending.append(self.pending.row_of[seq_id])
+                    last = 0
+                else:
+                    from_pending.append(-1)
+                tokens.append(last)
                 positions.append(pos)
                 context_lens.append(seq_len if self.sliding_window is None else min(seq_len, self.sliding_window))
                 table = meta.block_tables[seq_id]
@@ -187,6 +200,7 @@ class ModelRunner:
             padded = _get_graph_batch_size(batch)
             for _ in range(padded - batch):
                 tokens.append(0)
+                from_pending.append(-1)
                 positions.append(0)
                 slots.append(_PAD_SLOT_ID)
                 context_lens.append(1)
@@ -200,8 +214,12 @@ class ModelRunner:
             context_lens=self._to_device(np.asarray(context_lens, dtype=np.int32), torch.int32),
             block_tables=self._to_device(_pad_2d(tables, width, 0, np.int32), torch.int32),
             use_cuda_graph=use_graph, kv_cache_dtype=self.kv_cache_dtype)
-        return (self._to_device(np.asarray(tokens, dtype=np.int64).reshape(-1, 1), torch.long),
-                self._to_device(np.asarray(positions, dtype=np.int64).reshape(-1, 1), torch.long), md)
+        token_tensor = self._to_device(np.asarray(tokens, dtype=np.int64).reshape(-1, 1), torch.long)
+        if any(r >= 0 for r in from_pending):
+            src = self._to_device(np.asarray(from_pending, dtype=np.int64), torch.long)
+            on_device = self.pending.next_ids.index_select(0, src.clamp(min=0)).view(-1, 1)
+            token_tensor = torch.where((src >= 0).view(-1, 1), on_device, token_tensor)
+        return (token_tensor, self._to_device(np.asarray(positions, dtype=np.int64).reshape(-1, 1), torch.long), md)
 
     # ---------------------------------------------------------------- sampling
     def _prepare_sample(self, metas: List[SequenceGroupMetadata], last_token_rows: Optional[List[int]]):
@@ -235,7 +253,9 @@ class ModelRunner:
     # --------------------------------------------------------------- execution
     @torch.inference_mode()
     def execute_model(self, metas: List[SequenceGroupMetadata], kv_caches, blocks_to_nw=None,
-                      prompt_layout: str = "packed") -> Optional[SamplerOutput]:
+                      prompt_layout: str = "packed", defer: bool = False):
+        """``defer``: return the step's ``PendingSamples`` (tokens still on the device) instead of a
+        ``SamplerOutput``; the next decode step takes unknown last tokens from it."""
         is_prompt = metas[0].is_prompt
         if is_prompt:
             if prompt_layout == "packed":
@@ -255,7 +275,10 @@ class ModelRunner:
             hidden = self.graph_runners[tokens.shape[0]](tokens, positions, kv_caches, md)
         else:
             hidden = self.model(tokens.view(-1), positions.view(-1), kv_caches, md)
-        return self.model.sample(hidden, sampling_md)
+        sampling_md.defer = defer
+        result = self.model.sample(hidden, sampling_md)
+        self.pending = result if defer else None
+        return result
 
     @torch.inference_mode()
     def profile_run(self) -> None:

@@ -184,8 +184,9 @@ class Worker:
                       blocks_to_swap_out: Optional[Dict[int, int]] = None,
                       blocks_to_copy: Optional[Dict[int, List[int]]] = None,
                       blocks_to_nw: Optional[Dict[int, List[Tuple[int, int]]]] = None,
-                      nw_epochs: Optional[Dict[int, int]] = None) -> Optional[SamplerOutput]:
-        """``nw_epochs`` (optional) gives the hand-off count of every slot in ``blocks_to_nw`` as the
+                      nw_epochs: Optional[Dict[int, int]] = None, defer: bool = False):
+        """``defer`` leaves the sampled tokens on the device (see ModelRunner.execute_model).
+        ``nw_epochs`` (optional) gives the hand-off count of every slot in ``blocks_to_nw`` as the
         engine counts it; without it each side counts its own signals / waits."""
         blocks_to_nw = blocks_to_nw or {}
         nw_epochs = nw_epochs or {}
@@ -197,7 +198,7 @@ class Worker:
         if blocks_to_nw and comm is not None and self.is_token_worker() and not is_prompt:
             for sem_id in blocks_to_nw:
                 comm.wait(sem_id, nw_epochs.get(sem_id))
-        output = self.model_runner.execute_model(seq_group_metadata_list, self.gpu_cache, blocks_to_nw)
+        output = self.model_runner.execute_model(seq_group_metadata_list, self.gpu_cache, blocks_to_nw, defer=defer)
         if blocks_to_nw and comm is not None and self.is_prompt_worker() and is_prompt:
             for sem_id in blocks_to_nw:
                 comm.signal_and_flush(sem_id, nw_epochs.get(sem_id))
