@@ -84,7 +84,7 @@ def test_gptq_dequant_bit_exact(mode, group):
 GEMM_SHAPES = [          # (M, K, N, group)
     (1, 128, 128, 128), (1, 2560, 5120, 128), (3, 256, 136, 32), (7, 1024, 520, 64), (8, 5120, 7680, 128),
     (16, 512, 384, 512), (32, 6912, 1024, 128), (33, 512, 256, 128), (50, 1024, 384, 64), (64, 2048, 1000, 128),
-    (100, 512, 264, 32), (200, 1024, 512, 128), (5, 96, 64, 32), (40, 160, 72, 16),
+    (100, 512, 264, 32), (200, 1024, 512, 128), (5, 96, 64, 32), (40, 160, 72, 32), (130, 384, 200, 64),
 ]
 
 

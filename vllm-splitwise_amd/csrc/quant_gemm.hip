@@ -135,12 +135,16 @@ template <int MT, int CP, int PF>
 __device__ __forceinline__ void gptq_stream(f32x16 (&acc)[MT][CP], const uint16_t* __restrict__ a,
                                             const uint32_t* __restrict__ qweight, const uint32_t* __restrict__ qzeros,
                                             const uint16_t* __restrict__ scales, int M, int N, int K, int group_size,
-                                            int m0, int ncl, int s_begin, int s_end) {
+                                            int m0, int ncl, int p_begin, int p_end) {
+  // The unit of streaming is a PAIR of 16-k steps (32 k).  Within a pair the k order is permuted
+  // so that a lane's two A fragments are 32 contiguous bytes and the two halves of the wave read
+  // the whole 64 bytes of a row: lane (j, half), sub-step i covers k = 32 d + 16 half + 8 i .. + 7,
+  // i.e. weight word row 4 d + 2 half + i.  A and W use the same order, so the sum is unchanged.
   using wvec = typename WordVec<CP>::type;
   using svec = typename WordVec<CP>::scale_t;
   const int lane = threadIdx.x & 63;
   const int j = lane & 31, half = lane >> 5;
-  const int spg = group_size / 16;                    // steps per group
+  const int ppg = group_size / 32;                    // pairs per group
 #pragma unroll
   for (int t = 0; t < MT; ++t)
 #pragma unroll
@@ -150,36 +154,40 @@ __device__ __forceinline__ void gptq_stream(f32x16 (&acc)[MT][CP], const uint16_
 
   const uint16_t* ap[MT];
 #pragma unroll
-  for (int t = 0; t < MT; ++t) ap[t] = a + (size_t)min(m0 + 32 * t + j, M - 1) * K + 8 * half;
-  const uint32_t* wp = qweight + (size_t)half * N + ncl;
+  for (int t = 0; t < MT; ++t) ap[t] = a + (size_t)min(m0 + 32 * t + j, M - 1) * K + 16 * half;
+  const uint32_t* wp = qweight + (size_t)(2 * half) * N + ncl;
   const int zshift = 4 * (ncl & 7);                   // this lane's zero nibbles inside the zeros word
 
   // register ring; slot indices are compile-time so that nothing is spilled
-  wvec wq[PF];
-  f16x8 af[PF][MT];
+  wvec wq[PF][2];
+  f16x8 af[PF][MT][2];
   uint32_t zq[PF];
   svec sq[PF];
   GptqCol col[CP];
-  int i_group = s_begin / spg;                        // group at the issue cursor
-  int i_boundary = (i_group + 1) * spg;               // first step of the next group, issue side
+  int i_group = p_begin / ppg;                        // group at the issue cursor
+  int i_boundary = (i_group + 1) * ppg;               // first pair of the next group, issue side
   int c_boundary = i_boundary;                        // same, consume side
 
-  auto issue = [&](auto SLOT, int s) {
+  auto issue = [&](auto SLOT, int d) {
     constexpr int slot = decltype(SLOT)::value;
-    if (s >= s_end) return;
-    wq[slot] = *reinterpret_cast<const wvec*>(wp + (size_t)(2 * s) * N);
+    if (d >= p_end) return;
+    wq[slot][0] = *reinterpret_cast<const wvec*>(wp + (size_t)(4 * d) * N);
+    wq[slot][1] = *reinterpret_cast<const wvec*>(wp + (size_t)(4 * d + 1) * N);
 #pragma unroll
-    for (int t = 0; t < MT; ++t) af[slot][t] = *reinterpret_cast<const f16x8*>(ap[t] + 16 * s);
-    if (s == s_begin || s == i_boundary) {            // wave-uniform: the first step of a group carries its data
-      if (s == i_boundary) { ++i_group; i_boundary += spg; }
+    for (int t = 0; t < MT; ++t) {
+      af[slot][t][0] = *reinterpret_cast<const f16x8*>(ap[t] + 32 * d);
+      af[slot][t][1] = *reinterpret_cast<const f16x8*>(ap[t] + 32 * d + 8);
+    }
+    if (d == p_begin || d == i_boundary) {            // wave-uniform: the first pair of a group carries its data
+      if (d == i_boundary) { ++i_group; i_boundary += ppg; }
       zq[slot] = qzeros[(size_t)i_group * (N / 8) + ncl / 8];
       sq[slot] = *reinterpret_cast<const svec*>(scales + (size_t)i_group * N + ncl);
     }
   };
-  auto consume = [&](auto SLOT, int s) {
+  auto consume = [&](auto SLOT, int d) {
     constexpr int slot = decltype(SLOT)::value;
-    if (s == s_begin || s == c_boundary) {
-      if (s == c_boundary) c_boundary += spg;
+    if (d == p_begin || d == c_boundary) {
+      if (d == c_boundary) c_boundary += ppg;
       const uint32_t z = zq[slot] >> zshift;
       if constexpr (CP == 4) {
         col[0] = gptq_col((z & 0xfu) + 1, (uint16_t)(sq[slot].x & 0xffffu));
@@ -191,24 +199,27 @@ __device__ __forceinline__ void gptq_stream(f32x16 (&acc)[MT][CP], const uint16_
         col[1] = gptq_col(((z >> 4) & 0xfu) + 1, (uint16_t)(sq[slot] >> 16));
       }
     }
-    uint32_t w[CP];
-    if constexpr (CP == 4) { w[0] = wq[slot].x; w[1] = wq[slot].y; w[2] = wq[slot].z; w[3] = wq[slot].w; }
-    else { w[0] = wq[slot].x; w[1] = wq[slot].y; }
 #pragma unroll
-    for (int cc = 0; cc < CP; ++cc) {
-      const f16x8 b = gptq_dequant8(w[cc], col[cc]);
+    for (int i = 0; i < 2; ++i) {
+      uint32_t w[CP];
+      if constexpr (CP == 4) { w[0] = wq[slot][i].x; w[1] = wq[slot][i].y; w[2] = wq[slot][i].z; w[3] = wq[slot][i].w; }
+      else { w[0] = wq[slot][i].x; w[1] = wq[slot][i].y; }
 #pragma unroll
-      for (int t = 0; t < MT; ++t)
-        acc[t][cc] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[slot][t], b, acc[t][cc], 0, 0, 0);
+      for (int cc = 0; cc < CP; ++cc) {
+        const f16x8 b = gptq_dequant8(w[cc], col[cc]);
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+          acc[t][cc] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[slot][t][i], b, acc[t][cc], 0, 0, 0);
+      }
     }
   };
-  static_for<PF>([&](auto SLOT) { issue(SLOT, s_begin + decltype(SLOT)::value); });
-  for (int s = s_begin; s < s_end; s += PF) {
+  static_for<PF>([&](auto SLOT) { issue(SLOT, p_begin + decltype(SLOT)::value); });
+  for (int d = p_begin; d < p_end; d += PF) {
     static_for<PF>([&](auto SLOT) {
       constexpr int i = decltype(SLOT)::value;
-      if (s + i < s_end) {
-        consume(SLOT, s + i);
-        issue(SLOT, s + i + PF);
+      if (d + i < p_end) {
+        consume(SLOT, d + i);
+        issue(SLOT, d + i + PF);
       }
     });
   }
@@ -295,18 +306,21 @@ template <int MT, int CP, int PF>
 __global__ void __launch_bounds__(kGemmWaves * 64)
 gptq_gemm_kwaves_kernel(uint16_t* __restrict__ c, const uint16_t* __restrict__ a, const uint32_t* __restrict__ qweight,
                         const uint32_t* __restrict__ qzeros, const uint16_t* __restrict__ scales, int M, int N, int K,
-                        int group_size, int ksplit, float* __restrict__ partials, int32_t* __restrict__ counters) {
+                        int group_size, int ksplit, int row_tiles, float* __restrict__ partials,
+                        int32_t* __restrict__ counters) {
   extern __shared__ __attribute__((aligned(16))) float red[];
   __shared__ int s_last;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int half = lane >> 5;
-  const int ncol = blockIdx.x * 32 * CP + CP * (lane & 31);
+  // row tiles of one column tile are neighbours in launch order: they stream the same weights
+  const int col_tile = blockIdx.x / row_tiles, row_tile = blockIdx.x % row_tiles;
+  const int ncol = col_tile * 32 * CP + CP * (lane & 31);
   const bool col_ok = ncol < N;
-  const int m0 = blockIdx.y * 32 * MT;
-  const int steps = K / 16;
+  const int m0 = row_tile * 32 * MT;
+  const int pairs = K / 32;
   const int nw = ksplit * kGemmWaves, wg = blockIdx.z * kGemmWaves + wave;
-  const int s_begin = (int)((int64_t)steps * wg / nw), s_end = (int)((int64_t)steps * (wg + 1) / nw);
+  const int s_begin = (int)((int64_t)pairs * wg / nw), s_end = (int)((int64_t)pairs * (wg + 1) / nw);
 
   f32x16 acc[MT][CP];
   gptq_stream<MT, CP, PF>(acc, a, qweight, qzeros, scales, M, N, K, group_size, m0, col_ok ? ncol : 0, s_begin, s_end);
@@ -339,8 +353,8 @@ gptq_gemm_kwaves_kernel(uint16_t* __restrict__ c, const uint16_t* __restrict__ a
     return m0 + 32 * t + 16 * pass + 8 * (wave >> 2) + 4 * half + (wave & 3);
   };
   auto val_of = [&](int i, int cc) { return vals[i][cc]; };
-  combine_and_store<CP, 2 * MT>(val_of, row_of, col_ok, ncol, c, M, N, ksplit, partials, counters,
-                                blockIdx.y * gridDim.x + blockIdx.x, &s_last);
+  combine_and_store<CP, 2 * MT>(val_of, row_of, col_ok, ncol, c, M, N, ksplit, partials, counters, blockIdx.x,
+                                &s_last);
 }
 
 // Variant "tiled" (more than 32 rows of A): grid (groups of 8 column tiles, row tiles of 32*MT,
@@ -656,7 +670,7 @@ __global__ void awq_dequantize_kernel(uint16_t* __restrict__ out, const uint32_t
 constexpr int kAwqRow = 512 + 16;                   // bytes per image row (pad: rows land on different banks)
 constexpr int kAwqImage = 16 * kAwqRow;
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 2)
 awq_gemm_kernel(uint16_t* __restrict__ c, const uint16_t* __restrict__ a, const uint32_t* __restrict__ qweight,
                 const uint16_t* __restrict__ scales, const uint32_t* __restrict__ qzeros, int M, int N, int K,
                 int group_size, int ksplit, float* __restrict__ partials, int32_t* __restrict__ counters) {
@@ -690,28 +704,31 @@ awq_gemm_kernel(uint16_t* __restrict__ c, const uint16_t* __restrict__ a, const 
 
   AwqCols cols;
   int cur_group = -1;
-  uint32_t wq[2][8];
-  f16x8 af[2];
-  auto load_step = [&](auto BUF, int s) {
-    constexpr int buf = decltype(BUF)::value;
+  constexpr int PF = 4;                               // 16-k steps of weight words in flight per wave
+  uint32_t wq[PF][8];
+  f16x8 af[PF];
+  auto load_step = [&](auto SLOT, int s) {
+    constexpr int slot = decltype(SLOT)::value;
+    if (s >= s_end) return;
 #pragma unroll
-    for (int t = 0; t < 8; ++t) wq[buf][t] = qweight[(size_t)(16 * s + 2 * t + half) * nw + wcl];
-    af[buf] = *reinterpret_cast<const f16x8*>(ap + 16 * s);
+    for (int t = 0; t < 8; ++t) wq[slot][t] = qweight[(size_t)(16 * s + 2 * t + half) * nw + wcl];
+    af[slot] = *reinterpret_cast<const f16x8*>(ap + 16 * s);
   };
-  auto run_step = [&](auto BUF, int s) {
-    constexpr int buf = decltype(BUF)::value;
+  auto run_step = [&](auto SLOT, int s) {
+    constexpr int slot = decltype(SLOT)::value;
     const int g = 16 * s / group_size;
     if (g != cur_group) {                             // wave-uniform; group data is L2-resident
       cols = awq_cols(qzeros[(size_t)g * nw + wcl], *reinterpret_cast<const uint4*>(scales + (size_t)g * N + 8 * wcl));
       cur_group = g;
     }
-    if (s + 1 < s_end) load_step(std::integral_constant<int, buf ^ 1>{}, s + 1);
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
-      uint4 d = awq_dequant8(wq[buf][t], cols);
+      uint4 d = awq_dequant8(wq[slot][t], cols);
       if (!w_ok) d = make_uint4(0, 0, 0, 0);
       *reinterpret_cast<uint4*>(image + (2 * t + half) * kAwqRow + 16 * j) = d;
     }
+    const f16x8 a_frag = af[slot];
+    load_step(SLOT, s + PF);                          // the slot's registers are free again
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 #pragma unroll
     for (int cb = 0; cb < 8; ++cb) {
@@ -721,14 +738,16 @@ awq_gemm_kernel(uint16_t* __restrict__ c, const uint16_t* __restrict__ a, const 
       union { struct { i16x4 a, b; } p; f16x8 f; } bf;
       bf.p.a = lo;
       bf.p.b = hi;
-      acc[0][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[buf], bf.f, acc[0][cb], 0, 0, 0);
+      acc[0][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_frag, bf.f, acc[0][cb], 0, 0, 0);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");    // the image is rewritten next step
   };
-  if (s_begin < s_end) load_step(std::integral_constant<int, 0>{}, s_begin);
-  for (int s = s_begin; s < s_end; s += 2) {
-    run_step(std::integral_constant<int, 0>{}, s);
-    if (s + 1 < s_end) run_step(std::integral_constant<int, 1>{}, s + 1);
+  static_for<PF>([&](auto SLOT) { load_step(SLOT, s_begin + decltype(SLOT)::value); });
+  for (int s = s_begin; s < s_end; s += PF) {
+    static_for<PF>([&](auto SLOT) {
+      constexpr int i = decltype(SLOT)::value;
+      if (s + i < s_end) run_step(SLOT, s + i);
+    });
   }
   // accumulator cb holds column n0 + 32*cb + j; the four waves' sums meet in LDS (which reuses
   // the image memory) in four passes of 4 accumulator rows each.
@@ -902,7 +921,7 @@ int sw_gptq_gemm(void* c, const void* a, const uint32_t* qweight, const uint32_t
     return SW_OK;
   }
   const int group_size = K / groups;
-  SW_CHECK_ARG(group_size % 16 == 0, "gptq_gemm: group size %d is not a multiple of 16", group_size);
+  SW_CHECK_ARG(group_size % 32 == 0, "gptq_gemm: group size %d is not a multiple of 32", group_size);
   SW_CHECK_ARG(workspace != nullptr && workspace_bytes >= kCounterBytes,
                "gptq_gemm: workspace of at least %d bytes required", kCounterBytes);
   int32_t* counters = static_cast<int32_t*>(workspace);
@@ -920,12 +939,15 @@ int sw_gptq_gemm(void* c, const void* a, const uint32_t* qweight, const uint32_t
     ap = a_perm;
   }
   float* partials = reinterpret_cast<float*>(ws + kCounterBytes);
-  int cp = 2, mt = M > 32 ? 2 : 1;
-  bool tiled = M > 64 && K % kChunkK == 0;
+  // up to 128 rows: one row tile per workgroup, k split across its waves (every weight word is
+  // unpacked once); 129..256 rows: the LDS-tiled kernel, whose 8 waves share each A chunk
+  int cp = 2, mt = M > 64 ? 4 : M > 32 ? 2 : 1;
+  bool tiled = M > 128 && K % kChunkK == 0 && group_size % 16 == 0;
   if (const char* env = getenv("SW_QUANT_CP")) cp = atoi(env) == 4 ? 4 : 2;          // experiments only
   if (const char* env = getenv("SW_QUANT_MT")) mt = atoi(env);
   if (const char* env = getenv("SW_QUANT_TILED")) tiled = atoi(env) != 0 && K % kChunkK == 0;
-  if (mt > 2) mt = 2;
+  if (mt == 3 || mt > 4) mt = 4;
+  if (tiled && mt > 2) mt = 2;
   const int row_tiles = (M + 32 * mt - 1) / (32 * mt);
   if (tiled) {
     const int tile_cols = 32 * cp * kGemmWaves;
@@ -943,15 +965,22 @@ int sw_gptq_gemm(void* c, const void* a, const uint32_t* qweight, const uint32_t
 #undef SW_GPTQ_TILED
   } else {
     const int col_tiles = (N + 32 * cp - 1) / (32 * cp);
-    const int ks = pick_ksplit(col_tiles * row_tiles, K / 16, 8, M, N, avail, kGemmWaves, 256);
-    const dim3 grid(col_tiles, row_tiles, ks);
+    const int ks = pick_ksplit(col_tiles * row_tiles, K / 32, 4, M, N, avail, kGemmWaves, 256);
+    const dim3 grid(col_tiles * row_tiles, 1, ks);
     const size_t lds = (size_t)kGemmWaves * mt * cp * 8 * 64 * 4;
-#define SW_GPTQ_KWAVES(MT_, CP_)                                                                                     \
-  hipLaunchKernelGGL((gptq_gemm_kwaves_kernel<MT_, CP_, 8>), grid, dim3(kGemmWaves * 64), lds, st, out, ap, qweight, \
-                     qzeros, sp, M, N, K, group_size, ks, partials, counters)
-    if (mt == 1 && cp == 2) SW_GPTQ_KWAVES(1, 2);
-    else if (mt == 1) SW_GPTQ_KWAVES(1, 4);
-    else SW_GPTQ_KWAVES(2, 2);
+#define SW_GPTQ_KWAVES(MT_, CP_, PF_)                                                                             \
+  do {                                                                                                            \
+    auto kern = gptq_gemm_kwaves_kernel<MT_, CP_, PF_>;                                                           \
+    if (lds > 64 * 1024)                                                                                          \
+      SW_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                       \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                    \
+    hipLaunchKernelGGL(kern, grid, dim3(kGemmWaves * 64), lds, st, out, ap, qweight, qzeros, sp, M, N, K,         \
+                       group_size, ks, row_tiles, partials, counters);                                            \
+  } while (0)
+    if (mt == 1 && cp == 2) SW_GPTQ_KWAVES(1, 2, 4);
+    else if (mt == 1) SW_GPTQ_KWAVES(1, 4, 4);
+    else if (mt == 2) SW_GPTQ_KWAVES(2, 2, 4);
+    else SW_GPTQ_KWAVES(4, 2, 2);
 #undef SW_GPTQ_KWAVES
   }
   SW_CHECK_LAUNCH();
@@ -983,7 +1012,7 @@ int sw_awq_gemm(void* c, const void* a, const uint32_t* qweight, const void* sca
   int32_t* counters = static_cast<int32_t*>(workspace);
   float* partials = reinterpret_cast<float*>(static_cast<char*>(workspace) + kCounterBytes);
   const int col_tiles = (N + 255) / 256, row_tiles = (M + 31) / 32;
-  const int ks = pick_ksplit(col_tiles * row_tiles, K / 16, 8, M, N, workspace_bytes, 4, 384);
+  const int ks = pick_ksplit(col_tiles * row_tiles, K / 16, 8, M, N, workspace_bytes, 4, 512);
   const size_t lds = (size_t)4 * kAwqImage;           // four wave images; the reduction buffer reuses them
   static_assert(4 * 8 * 4 * 64 * 4 <= 4 * kAwqImage, "the reduction buffer must fit in the LDS images");
   hipLaunchKernelGGL(awq_gemm_kernel, dim3(col_tiles, row_tiles, ks), dim3(256), lds, static_cast<hipStream_t>(stream),
