@@ -49,7 +49,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=600)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--concurrency", type=int, default=128, help="requests kept in flight per replica")
+    ap.add_argument("--concurrency", type=int, default=256, help="requests kept in flight per replica")
     ap.add_argument("--model", default="llama-2-7b")
     ap.add_argument("--prompt-len", type=int, default=PROMPT_LEN)
     ap.add_argument("--decode-len", type=int, default=DECODE_LEN)
