@@ -257,6 +257,27 @@ int sw_rotary_embedding(const int64_t* positions, void* query, void* key,
 int sw_silu_and_mul(void* out, const void* input, int64_t num_tokens, int d,
                     int64_t input_stride, int act_dtype, void* stream);
 
+/* ------------------------------------------------------- all-reduce by direct peer reads
+ * Replaces csrc/custom_all_reduce.cu:12-148 / custom_all_reduce.cuh:341-548 (init_custom_ar,
+ * all_reduce_reg / all_reduce_unreg, dispose, meta_size), which the reference builds for CUDA only.
+ * Every rank owns ONE device allocation that its peers map (sw_ipc_*): at signal_off a signal area
+ * of sw_custom_ar_signal_bytes() bytes, zeroed before any rank's first call; at scratch_off and at
+ * staging_off max_bytes bytes each.  peer_bases[r] is rank r's allocation as mapped in this
+ * process (the local pointer for r == rank).  Calls must be made in the same order with the same
+ * sizes on every rank; one call at a time per state.                                          */
+int64_t sw_custom_ar_signal_bytes(void);
+int sw_custom_ar_init(void** peer_bases, int rank, int world, int64_t signal_off, int64_t scratch_off,
+                      int64_t staging_off, int64_t max_bytes, void** state_out);
+/* output = sum over ranks of their inputs (fp32 accumulation in the reference's rank order, one
+ * rounding; bitwise the same on every rank).  input: nbytes device bytes, copied to the staging
+ * area on the stream first; NULL (or the staging area itself) when the caller has produced the
+ * data there already (the reference's registered-buffer case).  act_dtype SW_F32 / SW_F16 /
+ * SW_BF16.  algorithm 0 = the reference's size rule (custom_all_reduce.cuh:521-527), 1 = one
+ * stage, 2 = reduce-scatter + all-gather.                                                     */
+int sw_custom_all_reduce(void* state, const void* input, void* output, int64_t nbytes, int act_dtype,
+                         int algorithm, void* stream);
+int sw_custom_ar_dispose(void* state);
+
 #ifdef __cplusplus
 }
 #endif

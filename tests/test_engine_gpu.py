@@ -115,6 +115,8 @@ def test_tensor_parallel_pools_match_cpu_model(split, monkeypatch):
     random.seed(3)
     llm = LLM("llama-tiny", tensor_parallel_size=2, sep_prompt_token=split, num_gpu_blocks_override=128,
               max_num_seqs=8, max_model_len=512, swap_space=0.01)
+    from splitwise_amd.model_executor import custom_all_reduce
+    assert custom_all_reduce.is_initialized()          # the pools' all-reduces run as direct peer reads
     try:
         vocab = llm.llm_engine.model_config.get_vocab_size()
         prompts = [[random.randrange(vocab) for _ in range(n)] for n in (5, 33, 64, 17, 100, 1, 48)]

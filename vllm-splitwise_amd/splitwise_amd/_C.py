@@ -62,6 +62,11 @@ _SIGNATURES = {
     "sw_kv_push": [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p],
     "sw_kv_signal": [_c_void_p, _c_int, ctypes.c_int32, _c_void_p],
     "sw_kv_wait": [_c_void_p, _c_int, ctypes.c_int32, _c_i64, _c_void_p, _c_void_p],
+    "sw_custom_ar_signal_bytes": [],
+    "sw_custom_ar_init": [ctypes.POINTER(_c_void_p), _c_int, _c_int, _c_i64, _c_i64, _c_i64, _c_i64,
+                          ctypes.POINTER(_c_void_p)],
+    "sw_custom_all_reduce": [_c_void_p, _c_void_p, _c_void_p, _c_i64, _c_int, _c_int, _c_void_p],
+    "sw_custom_ar_dispose": [_c_void_p],
     "sw_quant_gemm_workspace_bytes": [_c_int, _c_int, _c_int],
     "sw_gptq_shuffle": [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p],
     "sw_gptq_gemm": [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int,
@@ -72,7 +77,7 @@ _SIGNATURES = {
                     _c_void_p, _c_i64, _c_void_p],
     "sw_awq_dequantize": [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p],
 }
-_RESTYPES = {"sw_quant_gemm_workspace_bytes": _c_i64}     # everything else returns an int status
+_RESTYPES = {"sw_quant_gemm_workspace_bytes": _c_i64, "sw_custom_ar_signal_bytes": _c_i64}     # everything else returns an int status
 
 _lib = None
 
@@ -412,6 +417,31 @@ def ipc_close_mem_handle(dev_ptr: int) -> None:
     _check(load_library().sw_ipc_close_mem_handle(dev_ptr))
 
 
+# ------------------------------------------------------------------ all-reduce by peer reads
+def custom_ar_signal_bytes() -> int:
+    return int(load_library().sw_custom_ar_signal_bytes())
+
+
+def custom_ar_init(peer_bases: List[int], rank: int, signal_off: int, scratch_off: int, staging_off: int,
+                   max_bytes: int) -> int:
+    arr = (_c_void_p * len(peer_bases))(*peer_bases)
+    state = _c_void_p()
+    _check(load_library().sw_custom_ar_init(arr, rank, len(peer_bases), signal_off, scratch_off, staging_off,
+                                            max_bytes, ctypes.byref(state)))
+    return state.value
+
+
+def custom_all_reduce(state: int, inp: torch.Tensor, out: torch.Tensor, algorithm: int = 0) -> None:
+    if not (inp.is_contiguous() and out.is_contiguous()) or inp.shape != out.shape or inp.dtype != out.dtype:
+        raise RuntimeError("custom_all_reduce: input and output must be contiguous tensors of one shape and dtype")
+    _check(load_library().sw_custom_all_reduce(state, inp.data_ptr(), out.data_ptr(), inp.numel() * inp.element_size(),
+                                               _act_dtype(inp), algorithm, _stream(inp)))
+
+
+def custom_ar_dispose(state: int) -> None:
+    _check(load_library().sw_custom_ar_dispose(state))
+
+
 def kv_push(dst_base: int, src_base: int, offsets: List[int], nbytes: List[int], stream: int) -> None:
     n = len(offsets)
     if n == 0:
@@ -582,6 +612,12 @@ cache_ops = SimpleNamespace(
     copy_blocks=copy_blocks,
     swap_blocks=swap_blocks,
     convert_fp8_e5m2=convert_fp8_e5m2,
+)
+custom_ar = SimpleNamespace(
+    signal_bytes=custom_ar_signal_bytes,
+    init=custom_ar_init,
+    all_reduce=custom_all_reduce,
+    dispose=custom_ar_dispose,
 )
 kv_ops = SimpleNamespace(
     ipc_get_mem_handle=ipc_get_mem_handle,

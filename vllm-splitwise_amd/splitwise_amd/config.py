@@ -152,12 +152,13 @@ class ParallelConfig:
     a token pool of tensor_parallel_size ranks each (:433-443)."""
 
     def __init__(self, pipeline_parallel_size: int = 1, tensor_parallel_size: int = 1,
-                 sep_prompt_token: bool = False) -> None:
+                 sep_prompt_token: bool = False, disable_custom_all_reduce: bool = False) -> None:
         if pipeline_parallel_size > 1:
             raise NotImplementedError("Pipeline parallelism is not supported yet.")
         self.pipeline_parallel_size = pipeline_parallel_size
         self.tensor_parallel_size = tensor_parallel_size
         self.sep_prompt_token = sep_prompt_token
+        self.disable_custom_all_reduce = disable_custom_all_reduce
         self.world_size = pipeline_parallel_size * tensor_parallel_size
         self.num_prompt_workers = 0
         self.num_token_workers = 0

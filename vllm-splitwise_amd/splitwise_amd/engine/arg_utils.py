@@ -19,6 +19,7 @@ class EngineArgs:
     pipeline_parallel_size: int = 1
     tensor_parallel_size: int = 1
     sep_prompt_token: bool = False
+    disable_custom_all_reduce: bool = False
     block_size: int = 16
     enable_prefix_caching: bool = False
     swap_space: float = 4            # GiB
@@ -59,7 +60,7 @@ class EngineArgs:
                                    self.kv_cache_dtype, model_config.get_sliding_window(),
                                    self.enable_prefix_caching)
         parallel_config = ParallelConfig(self.pipeline_parallel_size, self.tensor_parallel_size,
-                                         self.sep_prompt_token)
+                                         self.sep_prompt_token, self.disable_custom_all_reduce)
         model_config.verify_with_parallel_config(parallel_config)
         scheduler_config = SchedulerConfig(self.max_num_batched_tokens, self.max_num_seqs,
                                            model_config.max_model_len, self.max_paddings,

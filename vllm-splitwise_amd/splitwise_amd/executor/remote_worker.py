@@ -58,6 +58,11 @@ def worker_loop(channel, cfg: Dict[str, Any], worker_cls=Worker) -> None:
             except Exception as exc:            # report and keep serving: the engine decides
                 channel.send(("error", f"{type(exc).__name__}: {exc}\n{traceback.format_exc()}"))
     finally:
+        try:
+            from ..model_executor.custom_all_reduce import destroy_custom_ar
+            destroy_custom_ar()
+        except Exception:
+            pass
         if worker is not None and worker.kvcache_comm_manager is not None:
             try:
                 worker.destroy_kvcache_comm()

@@ -51,6 +51,8 @@ def initialize_model_parallel(tensor_model_parallel_size: int = 1, sep_prompt_to
 
 def destroy_model_parallel() -> None:
     global _TP_GROUP, _STAGE_GROUP, _TP_WORLD, _TP_RANK, _HOST_STAGED
+    from .custom_all_reduce import destroy_custom_ar
+    destroy_custom_ar()
     _TP_GROUP = _STAGE_GROUP = None
     _TP_WORLD, _TP_RANK = 1, 0
     _HOST_STAGED = False
@@ -76,6 +78,11 @@ def tensor_model_parallel_all_reduce(x: torch.Tensor) -> torch.Tensor:
     """In-place SUM over the TP group (communication_op.py:19-43)."""
     if _TP_WORLD == 1:
         return x
+    # small messages: direct peer reads (communication_op.py:27-31 tries the same path first)
+    from .custom_all_reduce import custom_all_reduce
+    out = custom_all_reduce(x)
+    if out is not None:
+        return out
     if _HOST_STAGED and x.is_cuda:
         host = x.cpu()
         dist.all_reduce(host, group=_TP_GROUP)

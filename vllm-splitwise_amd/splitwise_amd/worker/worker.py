@@ -89,6 +89,13 @@ class Worker:
             dist.all_reduce(warm)                                      # warm-up (worker.py:452-455)
         parallel_state.initialize_model_parallel(self.parallel_config.tensor_parallel_size,
                                                  self.parallel_config.sep_prompt_token)
+        if (self.parallel_config.tensor_parallel_size > 1
+                and not getattr(self.parallel_config, "disable_custom_all_reduce", False)):
+            # worker.py:100-103 of the reference: small all-reduces go through direct peer reads
+            from ..model_executor.custom_all_reduce import init_custom_ar
+            init_custom_ar(parallel_state.get_tensor_model_parallel_rank(),
+                           self.parallel_config.tensor_parallel_size,
+                           parallel_state.get_tensor_model_parallel_group())
         self.init_kvcache_comm(self.kv_transport_init)
         torch.manual_seed(self.model_config.seed)
 
