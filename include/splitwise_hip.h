@@ -257,6 +257,25 @@ int sw_rotary_embedding(const int64_t* positions, void* query, void* key,
 int sw_silu_and_mul(void* out, const void* input, int64_t num_tokens, int d,
                     int64_t input_stride, int act_dtype, void* stream);
 
+/* ------------------------------------------------- prefill attention over a cached prefix
+ * Replaces the Triton kernels behind context_attention_fwd
+ * (vllm/model_executor/layers/attention/ops/prefix_prefill.py:10-745; caller
+ * PagedAttentionImpl.forward_prefix, ops/paged_attn.py:113-138): sequence i has ctx_lens[i]
+ * tokens already in the paged cache (block_tables row i) and new_lens[i] new tokens in rows
+ * [seq_starts[i], +new_lens[i]) of query / key / value; new token j attends to the whole
+ * context and to new tokens 0..j.  key_cache [blocks, num_kv_heads, head_size/8, block_size, 8],
+ * value_cache [blocks, num_kv_heads, head_size, block_size], 16-bit elements of the activation
+ * dtype, strides in elements; block_size a multiple of 4.  Other arguments as in
+ * sw_prefill_attention.                                                                      */
+int sw_context_attention(void* out, const void* query, const void* key, const void* value,
+                         const void* key_cache, const void* value_cache, const int32_t* block_tables,
+                         int max_blocks_per_seq, const int32_t* seq_starts, const int32_t* new_lens,
+                         const int32_t* ctx_lens, int num_seqs, int max_new_len, int num_heads,
+                         int num_kv_heads, int head_size, int block_size, float scale,
+                         const float* alibi_slopes, int64_t q_stride, int64_t k_stride, int64_t v_stride,
+                         int64_t out_stride, int64_t kv_block_stride, int64_t kv_head_stride,
+                         int sliding_window, int act_dtype, void* stream);
+
 /* ------------------------------------------------------- all-reduce by direct peer reads
  * Replaces csrc/custom_all_reduce.cu:12-148 / custom_all_reduce.cuh:341-548 (init_custom_ar,
  * all_reduce_reg / all_reduce_unreg, dispose, meta_size), which the reference builds for CUDA only.

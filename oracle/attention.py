@@ -93,3 +93,36 @@ def prefill_attention(query: torch.Tensor, key: torch.Tensor, value: torch.Tenso
         out[start:start + n] = torch.einsum("hqk,khd->qhd", p, v).to(dtype)
         start += n
     return out
+
+
+def context_attention(query: torch.Tensor, key: torch.Tensor, value: torch.Tensor, key_cache: torch.Tensor,
+                      value_cache: torch.Tensor, block_tables: torch.Tensor, new_lens: List[int],
+                      ctx_lens: List[int], alibi_slopes: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Prompt attention over a cached prefix: what ``context_attention_fwd`` computes
+    (vllm/model_executor/layers/attention/ops/prefix_prefill.py:10-745) and what its test compares
+    with (tests/kernels/test_prefix_prefill.py:126-176: causal "from bottom right" attention of the
+    new tokens over context + new tokens, scale D^-1/2).  query [T, H, D] and key/value [T, KVH, D]
+    hold the NEW tokens of all sequences back to back; the context lives in the paged caches.
+    ALiBi bias = slope * (key position - query position), as in _fwd_kernel_alibi (:433-618)."""
+    num_heads, kvh, head = query.shape[1], key.shape[1], query.shape[2]
+    g = num_heads // kvh
+    dtype = query.dtype
+    scale = head ** -0.5
+    out = torch.empty_like(query)
+    tables = block_tables.tolist()
+    start = 0
+    for i, (n, ctx) in enumerate(zip(new_lens, ctx_lens)):
+        kc, vc = gather_kv(key_cache, value_cache, tables[i], ctx) if ctx > 0 else (key[:0], value[:0])
+        k = torch.cat((kc, key[start:start + n])).float().repeat_interleave(g, dim=1)      # [ctx + n, H, D]
+        v = torch.cat((vc, value[start:start + n])).float().repeat_interleave(g, dim=1)
+        q = query[start:start + n].float()
+        w = scale * torch.einsum("qhd,khd->hqk", q, k)
+        qpos = torch.arange(n, dtype=torch.float32) + ctx
+        kpos = torch.arange(ctx + n, dtype=torch.float32)
+        if alibi_slopes is not None:
+            w = w + alibi_slopes.float().view(-1, 1, 1) * (kpos.view(1, 1, -1) - qpos.view(1, -1, 1))
+        w = w.masked_fill((kpos.view(1, -1) > qpos.view(-1, 1)).unsqueeze(0), float("-inf"))
+        p = torch.softmax(w, dim=-1).to(dtype).float()
+        out[start:start + n] = torch.einsum("hqk,khd->qhd", p, v).to(dtype)
+        start += n
+    return out

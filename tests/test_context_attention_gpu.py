@@ -1,0 +1,117 @@
+"""GPU parity: prompt attention over a cached prefix (sw_context_attention behind the reference's
+``context_attention_fwd`` argument list) vs the CPU oracle.  Set-up of the reference's own test
+(tests/kernels/test_prefix_prefill.py:31-118): random context and new-token lengths, a shuffled
+block table, q / k / v ~ U(-1e-3, 1e-3), MHA and GQA, block size 32 (and 16); that test compares
+with xformers (absent here), so the expected values come from the restatement in oracle/attention.py."""
+import random
+
+import pytest
+import torch
+
+from oracle import attention as oattn
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(num_heads, num_queries_per_kv, head_size, dtype, block_size, new_lens, ctx_lens, scale_inputs=1e-3, seed=0):
+    random.seed(seed)
+    torch.manual_seed(seed)
+    kvh = num_heads // num_queries_per_kv
+    bs = len(new_lens)
+    max_blocks = max(-(-c // block_size) for c in ctx_lens) + 2
+    cache_blocks = bs * max_blocks + 7
+    q = torch.empty(sum(new_lens), num_heads, head_size, dtype=dtype).uniform_(-scale_inputs, scale_inputs)
+    k = torch.empty(sum(new_lens), kvh, head_size, dtype=dtype).uniform_(-scale_inputs, scale_inputs)
+    v = torch.empty(sum(new_lens), kvh, head_size, dtype=dtype).uniform_(-scale_inputs, scale_inputs)
+    # never-written slots hold NaN bit patterns: they must not leak into the result
+    k_cache = torch.full((cache_blocks, kvh, head_size // 8, block_size, 8), float("nan"), dtype=dtype)
+    v_cache = torch.full((cache_blocks, kvh, head_size, block_size), float("nan"), dtype=dtype)
+    table = torch.randperm(cache_blocks)[:bs * max_blocks].view(bs, max_blocks).to(torch.int32)
+    for i, ctx in enumerate(ctx_lens):
+        kc = torch.empty(ctx, kvh, head_size, dtype=dtype).uniform_(-scale_inputs, scale_inputs)
+        vc = torch.empty(ctx, kvh, head_size, dtype=dtype).uniform_(-scale_inputs, scale_inputs)
+        for t in range(ctx):
+            blk, slot = int(table[i, t // block_size]), t % block_size
+            k_cache[blk, :, :, slot, :] = kc[t].view(kvh, head_size // 8, 8)
+            v_cache[blk, :, :, slot] = vc[t]
+    return q, k, v, k_cache, v_cache, table
+
+
+def _run(q, k, v, k_cache, v_cache, table, new_lens, ctx_lens, alibi=None, window=None):
+    from splitwise_amd import _C
+    starts, acc = [], 0
+    for n in new_lens:
+        starts.append(acc)
+        acc += n
+    dev = "cuda"
+    out = torch.zeros_like(q, device=dev)
+    seq_lens = [a + b for a, b in zip(new_lens, ctx_lens)]
+    _C.ops.context_attention_fwd(q.to(dev), k.to(dev), v.to(dev), out, k_cache.to(dev), v_cache.to(dev), table.to(dev),
+                                 torch.tensor(starts, dtype=torch.long, device=dev),
+                                 torch.tensor(seq_lens, dtype=torch.long, device=dev),
+                                 torch.tensor(ctx_lens, dtype=torch.long, device=dev), max(new_lens),
+                                 alibi.to(dev) if alibi is not None else None, window)
+    torch.cuda.synchronize()
+    return out.cpu()
+
+
+@pytest.mark.parametrize("num_heads,num_queries_per_kv", [(64, 1), (64, 8), (12, 1), (12, 3)])
+@pytest.mark.parametrize("head_size", [128, 64, 96])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_contexted_kv_attention(num_heads, num_queries_per_kv, head_size, dtype):
+    random.seed(1)
+    block_size = 32
+    new_lens = [random.randint(16, 300) for _ in range(4)]
+    ctx_lens = [random.randint(16, 400) for _ in range(4)]
+    q, k, v, kc, vc, table = _case(num_heads, num_queries_per_kv, head_size, dtype, block_size, new_lens, ctx_lens)
+    out = _run(q, k, v, kc, vc, table, new_lens, ctx_lens)
+    ref = oattn.context_attention(q, k, v, kc, vc, table, new_lens, ctx_lens)
+    assert not torch.isnan(out.float()).any()
+    # the reference's bound on these inputs is atol 1e-6 (test_prefix_prefill.py:176); outputs are ~1e-5
+    torch.testing.assert_close(out.float(), ref.float(), atol=1e-6, rtol=1e-2)
+
+
+@pytest.mark.parametrize("block_size", [16, 32])
+@pytest.mark.parametrize("use_alibi", [False, True])
+def test_edge_lengths_alibi_and_unit_scale(block_size, use_alibi):
+    """No context at all, context of one token, context ending on and off block boundaries, a single
+    new token; inputs of the magnitude the model produces (tolerance of the prompt-attention tests)."""
+    dtype = torch.bfloat16
+    head = 128
+    new_lens = [1, 33, 64, 5, 200, 31]
+    ctx_lens = [64, 0, 1, 31, 333, 96]
+    s = head ** -0.5
+    q, k, v, kc, vc, table = _case(8, 2, head, dtype, block_size, new_lens, ctx_lens, scale_inputs=s, seed=3)
+    alibi = torch.randn(8, dtype=torch.float) * 0.1 if use_alibi else None
+    out = _run(q, k, v, kc, vc, table, new_lens, ctx_lens, alibi)
+    ref = oattn.context_attention(q, k, v, kc, vc, table, new_lens, ctx_lens, alibi)
+    assert not torch.isnan(out.float()).any()
+    torch.testing.assert_close(out.float(), ref.float(), atol=1e-3, rtol=1e-5 if dtype == torch.float16 else 1e-2)
+
+
+def test_chunked_prompt_equals_whole_prompt():
+    """Size-independent property: running a prompt in two chunks (the first chunk written to the
+    cache, the second attending to it) gives the second chunk's rows of the one-shot result."""
+    from splitwise_amd import _C
+    torch.manual_seed(5)
+    dtype, h, kvh, d, bs = torch.float16, 16, 4, 128, 16
+    total, first = 1000, 592
+    s = d ** -0.5
+    q = torch.empty(total, h, d, dtype=dtype, device="cuda").uniform_(-s, s)
+    k = torch.empty(total, kvh, d, dtype=dtype, device="cuda").uniform_(-s, s)
+    v = torch.empty(total, kvh, d, dtype=dtype, device="cuda").uniform_(-s, s)
+    whole = torch.zeros_like(q)
+    i32 = lambda xs: torch.tensor(xs, dtype=torch.int32, device="cuda")
+    _C.ops.prefill_attention(whole, q, k, v, i32([0]), i32([total]), total, s)
+    blocks = -(-first // bs)
+    k_cache = torch.zeros(blocks + 3, kvh, d // 8, bs, 8, dtype=dtype, device="cuda")
+    v_cache = torch.zeros(blocks + 3, kvh, d, bs, dtype=dtype, device="cuda")
+    table = torch.randperm(blocks + 3)[:blocks].to(torch.int32)
+    slots = torch.tensor([int(table[t // bs]) * bs + t % bs for t in range(first)], dtype=torch.long, device="cuda")
+    _C.cache_ops.reshape_and_cache(k[:first], v[:first], k_cache, v_cache, slots, "auto")
+    part = torch.zeros(total - first, h, d, dtype=dtype, device="cuda")
+    _C.ops.context_attention_fwd(q[first:], k[first:], v[first:], part, k_cache, v_cache, table.view(1, -1).cuda(),
+                                 torch.tensor([0], device="cuda"), torch.tensor([total], device="cuda"),
+                                 torch.tensor([first], device="cuda"), total - first)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(part.float(), whole[first:].float(), atol=2e-3, rtol=1e-3)

@@ -56,14 +56,25 @@ __host__ __device__ constexpr int pf_vstride(int head) {          // bytes per V
   return (pf_dp(head) * 2 + 255) / 256 * 256 + 64;
 }
 
-template <typename act_t, int HEAD>
+// Keys and values that are already in the paged cache (a shared prefix, or the earlier chunks of
+// a prompt): every new token attends to all `ctx_lens[seq]` of them before the causal part.
+struct PfContext {
+  const uint16_t* k_cache;        // [blocks, KVH, HEAD/8, block_size, 8]
+  const uint16_t* v_cache;        // [blocks, KVH, HEAD, block_size]
+  const int32_t* block_tables;    // [num_seqs, max_blocks]
+  const int32_t* ctx_lens;        // [num_seqs]
+  int max_blocks, block_size;
+  int64_t k_block_stride, k_head_stride, v_block_stride, v_head_stride;   // elements
+};
+
+template <typename act_t, int HEAD, bool CTX>
 __global__ void __launch_bounds__(kPfWaves * 64)
 prefill_attention_kernel(uint16_t* __restrict__ out, const uint16_t* __restrict__ q,
                          const uint16_t* __restrict__ k, const uint16_t* __restrict__ v,
                          const int32_t* __restrict__ seq_starts, const int32_t* __restrict__ seq_lens,
                          int num_heads, int num_kv_heads, float scale,
                          const float* __restrict__ alibi_slopes, int64_t q_stride, int64_t k_stride,
-                         int64_t v_stride, int64_t out_stride, int sliding_window) {
+                         int64_t v_stride, int64_t out_stride, int sliding_window, PfContext cx) {
   using M = Mfma<act_t>;
   using frag = typename M::frag;
   constexpr int KS = HEAD / 16;                      // k-steps of the Q.K product
@@ -121,6 +132,105 @@ prefill_attention_kernel(uint16_t* __restrict__ out, const uint16_t* __restrict_
   const int tr_q = (lane & 15) >> 2, tr_p = lane & 3, tr_g = lane >> 4;
   const int tr_off = (4 * (tr_g >> 1) + tr_q) * VSTRIDE + (16 * (tr_g & 1) + 4 * tr_p) * 2;
 
+  // online-softmax update shared by both phases: `s` holds masked, scaled scores of 32 keys
+  frag pf[2];
+  auto softmax_step = [&](f32x16& s) {
+    float m_tile = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) m_tile = fmaxf(m_tile, s[r]);
+    m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 32, 64));
+    const float m_new = fmaxf(m_run, m_tile);
+    // a query row beyond the sequence (or a fully masked window tile) keeps m at -inf: use 0
+    const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
+    const float alpha = __expf(m_run - m_safe);
+    m_run = m_new;
+    float psum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float p = __expf(s[r] - m_safe);
+      const auto pr = M::cvt(p);                     // rounded to the activation dtype
+      psum += p;
+      pf[r >> 3][r & 7] = pr;
+    }
+    l_part = l_part * alpha + psum;
+#pragma unroll
+    for (int b = 0; b < DB; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[b][r] *= alpha;
+  };
+
+  int ctx = 0;
+  if constexpr (CTX) {
+    // ---- phase 1: the cached context.  Both operands come straight from the cache layouts: 8
+    // contiguous head elements of a key are one 16-byte group of the key cache, and 4 contiguous
+    // keys of one head element are 8 bytes of the value cache (= a piece of V^T).
+    ctx = cx.ctx_lens[seq];
+    const int32_t* table = cx.block_tables + (int64_t)seq * cx.max_blocks;
+    const int bs = cx.block_size;
+    const int q_abs = ctx + q_idx;
+    int c_begin = 0;
+    if (sliding_window > 0) c_begin = max(0, (ctx + q0 - sliding_window + 1) / kPfKeys * kPfKeys);
+    for (int k0 = c_begin; k0 < ctx; k0 += kPfKeys) {
+      f32x16 s;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = 0.f;
+      {
+        const int kk = min(k0 + col, ctx - 1);
+        const uint16_t* kp = cx.k_cache + (int64_t)table[kk / bs] * cx.k_block_stride +
+                             (int64_t)kv_head * cx.k_head_stride + (kk % bs) * 8 + (int64_t)half * bs * 8;
+        frag kf[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) kf[ks] = *reinterpret_cast<const frag*>(kp + (int64_t)(2 * ks) * bs * 8);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) s = M::run(kf[ks], qf[ks], s);
+      }
+      // V^T pieces: O^T row d = 32 b + col, keys k0 + 16 st + 8 g + 4 half .. + 3
+      uint2 vraw[2][DB][2];
+      const bool tail = k0 + kPfKeys > ctx;
+#pragma unroll
+      for (int st = 0; st < 2; ++st)
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          const int key0 = k0 + 16 * st + 8 * g + 4 * half;
+          const int kc = min(key0, ctx - 1);
+          const uint16_t* vp = cx.v_cache + (int64_t)table[kc / bs] * cx.v_block_stride +
+                               (int64_t)kv_head * cx.v_head_stride + (kc % bs);
+#pragma unroll
+          for (int b = 0; b < DB; ++b) {
+            const int d = 32 * b + col;
+            uint2 w = make_uint2(0, 0);
+            if (d < HEAD && key0 < ctx) w = *reinterpret_cast<const uint2*>(vp + (int64_t)d * bs);
+            if (tail) {                                // never-written slots may hold NaN bit patterns
+              if (key0 + 0 >= ctx) w.x &= 0xffff0000u;
+              if (key0 + 1 >= ctx) w.x &= 0x0000ffffu;
+              if (key0 + 2 >= ctx) w.y &= 0xffff0000u;
+              if (key0 + 3 >= ctx) w.y &= 0x0000ffffu;
+            }
+            vraw[st][b][g] = w;
+          }
+        }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        float x = s[r] * scale;
+        if (slope != 0.f) x += slope * (float)(key - q_abs);
+        bool ok = key < ctx;
+        if (sliding_window > 0) ok = ok && (q_abs - key < sliding_window);
+        s[r] = ok ? x : -INFINITY;
+      }
+      softmax_step(s);
+#pragma unroll
+      for (int st = 0; st < 2; ++st)
+#pragma unroll
+        for (int b = 0; b < DB; ++b) {
+          union { uint2 u[2]; frag f; } vf;
+          vf.u[0] = vraw[st][b][0];
+          vf.u[1] = vraw[st][b][1];
+          o[b] = M::run(vf.f, pf[st], o[b]);
+        }
+    }
+  }
+
   const int k_end = min(q0 + kPfRows, seq_len);      // causal: keys < k_end
   int k_begin = 0;
   if (sliding_window > 0) k_begin = max(0, (q0 - sliding_window + 1) / kPfKeys * kPfKeys);
@@ -158,7 +268,6 @@ prefill_attention_kernel(uint16_t* __restrict__ out, const uint16_t* __restrict_
 
     // ---- mask, online softmax (this lane: query q_idx, keys k0 + (r&3) + 8*(r>>2) + 4*half)
     const bool need_mask = (k0 + kPfKeys - 1 > q0) || (sliding_window > 0);
-    float m_tile = -INFINITY;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -170,28 +279,8 @@ prefill_attention_kernel(uint16_t* __restrict__ out, const uint16_t* __restrict_
         x = ok ? x : -INFINITY;
       }
       s[r] = x;
-      m_tile = fmaxf(m_tile, x);
     }
-    m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 32, 64));
-    const float m_new = fmaxf(m_run, m_tile);
-    // a query row beyond the sequence (or a fully masked window tile) keeps m at -inf: use 0
-    const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
-    const float alpha = __expf(m_run - m_safe);
-    m_run = m_new;
-    float psum = 0.f;
-    frag pf[2];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float p = __expf(s[r] - m_safe);
-      const auto pr = M::cvt(p);                     // rounded to the activation dtype
-      psum += p;
-      pf[r >> 3][r & 7] = pr;
-    }
-    l_part = l_part * alpha + psum;
-#pragma unroll
-    for (int b = 0; b < DB; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o[b][r] *= alpha;
+    softmax_step(s);
 
     // ---- O^T += V^T . P^T ; A operand element j <-> key 16*st + 8*(j>>2) + 4*half + (j&3)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -233,31 +322,27 @@ prefill_attention_kernel(uint16_t* __restrict__ out, const uint16_t* __restrict_
   }
 }
 
-template <typename act_t, int HEAD>
+template <typename act_t, int HEAD, bool CTX>
 int launch_prefill(void* out, const void* q, const void* k, const void* v, const int32_t* seq_starts,
                    const int32_t* seq_lens, int num_seqs, int max_seq_len, int num_heads, int num_kv_heads,
                    float scale, const float* alibi, int64_t q_stride, int64_t k_stride, int64_t v_stride,
-                   int64_t out_stride, int sliding_window, hipStream_t stream) {
+                   int64_t out_stride, int sliding_window, const PfContext& cx, hipStream_t stream) {
   const int rows_per_wg = kPfWaves * kPfRows;
   dim3 grid((max_seq_len + rows_per_wg - 1) / rows_per_wg, num_heads, num_seqs);
   const size_t smem = (size_t)kPfWaves * kPfKeys * pf_vstride(HEAD);
-  prefill_attention_kernel<act_t, HEAD><<<grid, kPfWaves * 64, smem, stream>>>(
+  prefill_attention_kernel<act_t, HEAD, CTX><<<grid, kPfWaves * 64, smem, stream>>>(
       static_cast<uint16_t*>(out), static_cast<const uint16_t*>(q), static_cast<const uint16_t*>(k),
       static_cast<const uint16_t*>(v), seq_starts, seq_lens, num_heads, num_kv_heads, scale, alibi, q_stride,
-      k_stride, v_stride, out_stride, sliding_window);
+      k_stride, v_stride, out_stride, sliding_window, cx);
   SW_CHECK_LAUNCH();
   return SW_OK;
 }
 
-}  // namespace sw
-
-extern "C" int sw_prefill_attention(void* out, const void* query, const void* key, const void* value,
-                                    const int32_t* seq_starts, const int32_t* seq_lens, int num_seqs,
-                                    int max_seq_len, int num_heads, int num_kv_heads, int head_size,
-                                    float scale, const float* alibi_slopes, int64_t q_stride,
-                                    int64_t k_stride, int64_t v_stride, int64_t out_stride,
-                                    int sliding_window, int act_dtype, void* stream) {
-  using namespace sw;
+int prefill_entry(void* out, const void* query, const void* key, const void* value, const int32_t* seq_starts,
+                  const int32_t* seq_lens, int num_seqs, int max_seq_len, int num_heads, int num_kv_heads,
+                  int head_size, float scale, const float* alibi_slopes, int64_t q_stride, int64_t k_stride,
+                  int64_t v_stride, int64_t out_stride, int sliding_window, int act_dtype, const PfContext* cx,
+                  void* stream) {
   if (num_seqs == 0 || max_seq_len == 0) return SW_OK;
   SW_CHECK_ARG(num_seqs > 0 && max_seq_len > 0 && num_heads > 0 && num_kv_heads > 0 &&
                    num_heads % num_kv_heads == 0, "prefill_attention: bad shape");
@@ -269,24 +354,73 @@ extern "C" int sw_prefill_attention(void* out, const void* query, const void* ke
                    reinterpret_cast<uintptr_t>(value) % 16 == 0 && reinterpret_cast<uintptr_t>(out) % 8 == 0,
                "prefill_attention: rows must be 16-byte aligned");
   hipStream_t s = static_cast<hipStream_t>(stream);
-#define SW_PF(HEAD)                                                                                       \
-  return act_dtype == SW_BF16                                                                             \
-             ? launch_prefill<bf16_t, HEAD>(out, query, key, value, seq_starts, seq_lens, num_seqs,       \
-                                            max_seq_len, num_heads, num_kv_heads, scale, alibi_slopes,    \
-                                            q_stride, k_stride, v_stride, out_stride, sliding_window, s)  \
-             : launch_prefill<f16_t, HEAD>(out, query, key, value, seq_starts, seq_lens, num_seqs,        \
-                                           max_seq_len, num_heads, num_kv_heads, scale, alibi_slopes,     \
-                                           q_stride, k_stride, v_stride, out_stride, sliding_window, s)
+  const PfContext none = {};
+#define SW_PF_T(T, HEAD)                                                                                        \
+  return cx ? launch_prefill<T, HEAD, true>(out, query, key, value, seq_starts, seq_lens, num_seqs, max_seq_len, \
+                                            num_heads, num_kv_heads, scale, alibi_slopes, q_stride, k_stride,   \
+                                            v_stride, out_stride, sliding_window, *cx, s)                       \
+            : launch_prefill<T, HEAD, false>(out, query, key, value, seq_starts, seq_lens, num_seqs,            \
+                                             max_seq_len, num_heads, num_kv_heads, scale, alibi_slopes,         \
+                                             q_stride, k_stride, v_stride, out_stride, sliding_window, none, s)
+#define SW_PF(HEAD)                        \
+  if (act_dtype == SW_BF16) {              \
+    SW_PF_T(bf16_t, HEAD);                 \
+  } else {                                 \
+    SW_PF_T(f16_t, HEAD);                  \
+  }
   switch (head_size) {
-    case 64: SW_PF(64);
-    case 80: SW_PF(80);
-    case 96: SW_PF(96);
-    case 112: SW_PF(112);
-    case 128: SW_PF(128);
-    case 256: SW_PF(256);
+    case 64: SW_PF(64)
+    case 80: SW_PF(80)
+    case 96: SW_PF(96)
+    case 112: SW_PF(112)
+    case 128: SW_PF(128)
+    case 256: SW_PF(256)
     default: break;
   }
 #undef SW_PF
+#undef SW_PF_T
   set_error("Unsupported head size: %d", head_size);
   return SW_ERR_INVALID;
+}
+
+}  // namespace sw
+
+extern "C" int sw_prefill_attention(void* out, const void* query, const void* key, const void* value,
+                                    const int32_t* seq_starts, const int32_t* seq_lens, int num_seqs,
+                                    int max_seq_len, int num_heads, int num_kv_heads, int head_size,
+                                    float scale, const float* alibi_slopes, int64_t q_stride,
+                                    int64_t k_stride, int64_t v_stride, int64_t out_stride,
+                                    int sliding_window, int act_dtype, void* stream) {
+  return sw::prefill_entry(out, query, key, value, seq_starts, seq_lens, num_seqs, max_seq_len, num_heads,
+                           num_kv_heads, head_size, scale, alibi_slopes, q_stride, k_stride, v_stride, out_stride,
+                           sliding_window, act_dtype, nullptr, stream);
+}
+
+extern "C" int sw_context_attention(void* out, const void* query, const void* key, const void* value,
+                                    const void* key_cache, const void* value_cache, const int32_t* block_tables,
+                                    int max_blocks_per_seq, const int32_t* seq_starts, const int32_t* new_lens,
+                                    const int32_t* ctx_lens, int num_seqs, int max_new_len, int num_heads,
+                                    int num_kv_heads, int head_size, int block_size, float scale,
+                                    const float* alibi_slopes, int64_t q_stride, int64_t k_stride, int64_t v_stride,
+                                    int64_t out_stride, int64_t kv_block_stride, int64_t kv_head_stride,
+                                    int sliding_window, int act_dtype, void* stream) {
+  using namespace sw;
+  SW_CHECK_ARG(key_cache && value_cache && block_tables && ctx_lens && max_blocks_per_seq > 0,
+               "context_attention: NULL cache, block table or context lengths");
+  SW_CHECK_ARG(block_size > 0 && block_size % 4 == 0, "Unsupported block size: %d", block_size);
+  SW_CHECK_ARG(head_size % 8 == 0 && kv_block_stride % 8 == 0 && kv_head_stride % 8 == 0 &&
+                   reinterpret_cast<uintptr_t>(key_cache) % 16 == 0 && reinterpret_cast<uintptr_t>(value_cache) % 16 == 0,
+               "context_attention: the caches must be 16-byte aligned with strides in multiples of 8 elements");
+  PfContext cx;
+  cx.k_cache = static_cast<const uint16_t*>(key_cache);
+  cx.v_cache = static_cast<const uint16_t*>(value_cache);
+  cx.block_tables = block_tables;
+  cx.ctx_lens = ctx_lens;
+  cx.max_blocks = max_blocks_per_seq;
+  cx.block_size = block_size;
+  cx.k_block_stride = cx.v_block_stride = kv_block_stride;
+  cx.k_head_stride = cx.v_head_stride = kv_head_stride;
+  return prefill_entry(out, query, key, value, seq_starts, new_lens, num_seqs, max_new_len, num_heads, num_kv_heads,
+                       head_size, scale, alibi_slopes, q_stride, k_stride, v_stride, out_stride, sliding_window,
+                       act_dtype, &cx, stream);
 }

@@ -62,6 +62,8 @@ _SIGNATURES = {
     "sw_kv_push": [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p],
     "sw_kv_signal": [_c_void_p, _c_int, ctypes.c_int32, _c_void_p],
     "sw_kv_wait": [_c_void_p, _c_int, ctypes.c_int32, _c_i64, _c_void_p, _c_void_p],
+    "sw_context_attention": [_c_void_p] * 7 + [_c_int] + [_c_void_p] * 3 + [_c_int] * 6 + [ctypes.c_float, _c_void_p]
+                            + [_c_i64] * 6 + [_c_int, _c_int, _c_void_p],
     "sw_custom_ar_signal_bytes": [],
     "sw_custom_ar_init": [ctypes.POINTER(_c_void_p), _c_int, _c_int, _c_i64, _c_i64, _c_i64, _c_i64,
                           ctypes.POINTER(_c_void_p)],
@@ -315,6 +317,43 @@ def prefill_attention(out: torch.Tensor, query: torch.Tensor, key: torch.Tensor,
             query.shape[2], float(scale), alibi_slopes.data_ptr() if alibi_slopes is not None else None,
             query.stride(0), key.stride(0), value.stride(0), out.stride(0),
             int(sliding_window) if sliding_window else 0, act, _stream(query)))
+
+
+def context_attention_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, o: torch.Tensor, k_cache: torch.Tensor,
+                          v_cache: torch.Tensor, b_loc: torch.Tensor, b_start_loc: torch.Tensor,
+                          b_seq_len: torch.Tensor, b_ctx_len: torch.Tensor, max_input_len: int,
+                          alibi_slopes: Optional[torch.Tensor] = None, sliding_window: Optional[int] = None) -> None:
+    """Prompt attention over a cached prefix plus new tokens, with the argument list of the
+    reference's Triton entry point (ops/prefix_prefill.py:621-632): q / o [T, H, D], k / v [T, KVH, D]
+    (new tokens only), k_cache [blocks, KVH, D/8, bs, 8], v_cache [blocks, KVH, D, bs], b_loc the
+    block table [B, max_blocks], b_start_loc the first new-token row of each sequence, b_seq_len
+    context + new tokens, b_ctx_len the cached tokens.  scale = D^-1/2 (:641)."""
+    _require_cuda(o, q, k, v, k_cache, v_cache, b_loc, b_start_loc, b_seq_len, b_ctx_len)
+    for t in (o, q, k, v):
+        if t.stride(2) != 1 or t.stride(1) != t.shape[2]:
+            raise RuntimeError("context_attention_fwd: heads must be contiguous")
+    if k_cache.dtype != q.dtype or v_cache.dtype != q.dtype:
+        raise RuntimeError("context_attention_fwd: the cache must hold the activation dtype")
+    if k_cache.dim() != 5 or k_cache.shape[4] != 8 or not k_cache.is_contiguous() or not v_cache.is_contiguous():
+        raise RuntimeError("context_attention_fwd: key cache [blocks, KVH, D/8, bs, 8] and value cache "
+                           "[blocks, KVH, D, bs], both contiguous")
+    head = q.shape[2]
+    block_size = v_cache.shape[3]
+    starts = b_start_loc.to(torch.int32)
+    ctx = b_ctx_len.to(torch.int32)
+    new = (b_seq_len.to(torch.int32) - ctx).contiguous()
+    table = b_loc.to(torch.int32).contiguous()
+    act = _act_dtype(q)
+    if alibi_slopes is not None:
+        alibi_slopes = alibi_slopes.to(device=q.device, dtype=torch.float32)
+    with torch.cuda.device(q.device):
+        _check(load_library().sw_context_attention(
+            o.data_ptr(), q.data_ptr(), k.data_ptr(), v.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(),
+            table.data_ptr(), table.shape[1], starts.data_ptr(), new.data_ptr(), ctx.data_ptr(), new.numel(),
+            int(max_input_len), q.shape[1], k.shape[1], head, block_size, float(head) ** -0.5,
+            alibi_slopes.data_ptr() if alibi_slopes is not None else None, q.stride(0), k.stride(0), v.stride(0),
+            o.stride(0), v_cache.stride(0), v_cache.stride(1), int(sliding_window) if sliding_window else 0, act,
+            _stream(q)))
 
 
 def _rows(t: torch.Tensor):
@@ -597,6 +636,7 @@ ops = SimpleNamespace(
     paged_attention_v1=paged_attention_v1,
     paged_attention_v2=paged_attention_v2,
     prefill_attention=prefill_attention,
+    context_attention_fwd=context_attention_fwd,
     rms_norm=rms_norm,
     fused_add_rms_norm=fused_add_rms_norm,
     rotary_embedding=rotary_embedding,

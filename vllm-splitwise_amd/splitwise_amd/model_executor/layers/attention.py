@@ -65,6 +65,19 @@ class PagedAttentionImpl:
         return workgroups >= 32 and max_context_len <= 2 * _PARTITION_SIZE
 
     @staticmethod
+    def forward_prefix(query, key, value, key_cache, value_cache, input_metadata: InputMetadata,
+                       alibi_slopes=None):
+        """Prompt attention of new tokens over a prefix that is already in the cache
+        (ops/paged_attn.py:113-138): query / key / value [T, heads, head_size] of the new tokens;
+        the metadata carries the block tables, the first row of each sequence (start_loc), the
+        total lengths (prompt_lens) and the cached lengths (context_lens)."""
+        output = torch.empty_like(query)
+        _C.ops.context_attention_fwd(query, key, value, output, key_cache, value_cache, input_metadata.block_tables,
+                                     input_metadata.start_loc, input_metadata.prompt_lens,
+                                     input_metadata.context_lens, input_metadata.max_seq_len, alibi_slopes)
+        return output
+
+    @staticmethod
     def forward_decode(query, key_cache, value_cache, input_metadata: InputMetadata, num_kv_heads: int,
                        scale: float, alibi_slopes: Optional[torch.Tensor], workspace=None) -> torch.Tensor:
         output = torch.empty_like(query)
