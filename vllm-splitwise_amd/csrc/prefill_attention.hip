@@ -18,8 +18,13 @@
 //     O^T += V^T . P^T (32x32 accumulator rows are the next product's k index); the A
 //     operand V^T is read from a row-major LDS image of the V tile with the transposing
 //     ds_read_b64_tr_b16, 4 keys per read.
-//   * K fragments (8 contiguous head elements of one key per lane) come straight from
-//     global memory / L2; every LDS byte is wave-private, so there is no barrier at all.
+//   * the 4 waves of a workgroup (128 query rows) share every stage of 32 keys: K and V rows go
+//     global -> registers (while the previous stage is in use) -> LDS, one barrier per stage;
+//     K fragments are 16-byte LDS reads (8 contiguous head elements of one key per lane).
+//   * scores live in the log2 domain (one v_exp_f32 per probability); the output accumulator
+//     is rescaled only when some lane's running maximum moved.
+//   * a cached prefix (sw_context_attention) is handled before the causal part, its K and V^T
+//     fragments loaded straight from the paged cache layouts.
 #include "common.cuh"
 #include <float.h>
 
@@ -49,11 +54,18 @@ template <> struct Mfma<f16_t> {
 
 constexpr int kPfWaves = 4;
 constexpr int kPfRows = 32;                          // query rows per wave
-constexpr int kPfKeys = 32;                          // keys per tile
+constexpr int kPfKeys = 32;                          // keys per score tile (one MFMA output block)
+constexpr int kPfStage = 32;                         // keys per shared LDS stage (a multiple of kPfKeys)
 
 __host__ __device__ constexpr int pf_dp(int head) { return (head + 31) / 32 * 32; }
 __host__ __device__ constexpr int pf_vstride(int head) {          // bytes per V row in LDS
   return (pf_dp(head) * 2 + 255) / 256 * 256 + 64;
+}
+__host__ __device__ constexpr int pf_kstride(int head) {          // bytes per K row in LDS: 16 rows on 64 distinct banks
+  return head * 2 + 16;
+}
+__host__ __device__ constexpr int pf_lds_bytes(int head) {        // two stages of a K and a V image
+  return 2 * kPfStage * (pf_kstride(head) + pf_vstride(head));
 }
 
 // Keys and values that are already in the paged cache (a shared prefix, or the earlier chunks of
@@ -86,17 +98,23 @@ prefill_attention_kernel(uint16_t* __restrict__ out, const uint16_t* __restrict_
   static_assert(HEAD % 16 == 0 && (kPfKeys * CPR) % 64 == 0, "unsupported head size");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
-  char* v_lds = smem + wave * (kPfKeys * VSTRIDE);
+  constexpr int KSTRIDE = pf_kstride(HEAD);
+  constexpr int CHUNKS = kPfStage * CPR;             // 16-byte pieces of one stage of K (and of V)
+  constexpr int LOADS = (CHUNKS + kPfWaves * 64 - 1) / (kPfWaves * 64);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  char* k_img = smem;                                // [2][kPfStage][KSTRIDE]
+  char* v_img = smem + 2 * kPfStage * KSTRIDE;       // [2][kPfStage][VSTRIDE]
 
   const int seq = blockIdx.z;
   const int head = blockIdx.y;
   const int seq_len = seq_lens[seq];
   // heavy (late) query tiles first: they have the longest key loops under the causal mask
-  const int q_tile = (gridDim.x - 1 - blockIdx.x) * kPfWaves + wave;
-  const int q0 = q_tile * kPfRows;
-  if (q0 >= seq_len) return;                         // wave-uniform
+  const int q_base = (gridDim.x - 1 - blockIdx.x) * kPfWaves * kPfRows;
+  if (q_base >= seq_len) return;                     // workgroup-uniform
+  const int q0 = q_base + wave * kPfRows;
+  const bool active = q0 < seq_len;                  // wave-uniform; idle waves still load tiles and meet barriers
   const int64_t row0 = seq_starts[seq];
   const int kv_head = head / (num_heads / num_kv_heads);
   const float slope = alibi_slopes ? alibi_slopes[head] : 0.f;
@@ -114,10 +132,11 @@ prefill_attention_kernel(uint16_t* __restrict__ out, const uint16_t* __restrict_
     for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const frag*>(qp + 16 * ks);
   }
 
-  // zero the LDS image once: pad columns HEAD..DP-1 must read as 0 (never written again)
+  // zero the V images once: pad columns HEAD..DP-1 must read as 0 (never written again)
   if constexpr (DP != HEAD) {
-    for (int i = lane; i < kPfKeys * VSTRIDE / 16; i += 64)
-      reinterpret_cast<uint4*>(v_lds)[i] = make_uint4(0, 0, 0, 0);
+    for (int i = tid; i < 2 * kPfStage * VSTRIDE / 16; i += kPfWaves * 64)
+      reinterpret_cast<uint4*>(v_img)[i] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
   }
 
   f32x16 o[DB];
@@ -131,8 +150,12 @@ prefill_attention_kernel(uint16_t* __restrict__ out, const uint16_t* __restrict_
   // columns 4p..4p+3 of a 4 x 16 block; group g covers O^T rows 16*(g&1).. of key half g>>1
   const int tr_q = (lane & 15) >> 2, tr_p = lane & 3, tr_g = lane >> 4;
   const int tr_off = (4 * (tr_g >> 1) + tr_q) * VSTRIDE + (16 * (tr_g & 1) + 4 * tr_p) * 2;
+  const int k_off = col * KSTRIDE + half * 16;       // this lane's K fragment inside a score tile
 
-  // online-softmax update shared by both phases: `s` holds masked, scaled scores of 32 keys
+  // Scores are kept in the log2 domain (scale and ALiBi slope carry a factor log2 e), so a
+  // probability is one v_exp_f32.  Online-softmax update shared by both phases: `s` holds the
+  // masked, scaled scores of 32 keys.
+  const float scale2 = scale * 1.4426950408889634f, slope2 = slope * 1.4426950408889634f;
   frag pf[2];
   auto softmax_step = [&](f32x16& s) {
     float m_tile = -INFINITY;
@@ -142,29 +165,32 @@ prefill_attention_kernel(uint16_t* __restrict__ out, const uint16_t* __restrict_
     const float m_new = fmaxf(m_run, m_tile);
     // a query row beyond the sequence (or a fully masked window tile) keeps m at -inf: use 0
     const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
-    const float alpha = __expf(m_run - m_safe);
-    m_run = m_new;
     float psum = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const float p = __expf(s[r] - m_safe);
+      const float p = __builtin_amdgcn_exp2f(s[r] - m_safe);
       const auto pr = M::cvt(p);                     // rounded to the activation dtype
       psum += p;
       pf[r >> 3][r & 7] = pr;
     }
-    l_part = l_part * alpha + psum;
+    // the running maximum rarely moves after the first tiles: rescale only when some lane's did
+    if (__builtin_amdgcn_ballot_w64(m_new != m_run) != 0) {
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_safe);
+      l_part *= alpha;
 #pragma unroll
-    for (int b = 0; b < DB; ++b)
+      for (int b = 0; b < DB; ++b)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) o[b][r] *= alpha;
+        for (int r = 0; r < 16; ++r) o[b][r] *= alpha;
+      m_run = m_new;
+    }
+    l_part += psum;
   };
 
-  int ctx = 0;
-  if constexpr (CTX) {
+  if (CTX && active) {
     // ---- phase 1: the cached context.  Both operands come straight from the cache layouts: 8
     // contiguous head elements of a key are one 16-byte group of the key cache, and 4 contiguous
     // keys of one head element are 8 bytes of the value cache (= a piece of V^T).
-    ctx = cx.ctx_lens[seq];
+    const int ctx = cx.ctx_lens[seq];
     const int32_t* table = cx.block_tables + (int64_t)seq * cx.max_blocks;
     const int bs = cx.block_size;
     const int q_abs = ctx + q_idx;
@@ -209,14 +235,19 @@ prefill_attention_kernel(uint16_t* __restrict__ out, const uint16_t* __restrict_
             vraw[st][b][g] = w;
           }
         }
+      if (!tail && slope == 0.f && sliding_window <= 0) {          // wave-uniform: nothing to mask
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        float x = s[r] * scale;
-        if (slope != 0.f) x += slope * (float)(key - q_abs);
-        bool ok = key < ctx;
-        if (sliding_window > 0) ok = ok && (q_abs - key < sliding_window);
-        s[r] = ok ? x : -INFINITY;
+        for (int r = 0; r < 16; ++r) s[r] *= scale2;
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          float x = s[r] * scale2;
+          if (slope != 0.f) x += slope2 * (float)(key - q_abs);
+          bool ok = key < ctx;
+          if (sliding_window > 0) ok = ok && (q_abs - key < sliding_window);
+          s[r] = ok ? x : -INFINITY;
+        }
       }
       softmax_step(s);
 #pragma unroll
@@ -231,74 +262,102 @@ prefill_attention_kernel(uint16_t* __restrict__ out, const uint16_t* __restrict_
     }
   }
 
-  const int k_end = min(q0 + kPfRows, seq_len);      // causal: keys < k_end
+  // ---- phase 2: the new tokens, causal.  The workgroup's 4 waves (128 query rows) share every
+  // K / V stage of 64 keys through LDS: global -> registers while the previous stage is being
+  // used, registers -> LDS, one barrier per stage.
+  const int k_end = min(q0 + kPfRows, seq_len);      // this wave's keys: < k_end
   int k_begin = 0;
   if (sliding_window > 0) k_begin = max(0, (q0 - sliding_window + 1) / kPfKeys * kPfKeys);
+  const int wg_end = min(q_base + kPfWaves * kPfRows, seq_len);
+  int wg_begin = 0;
+  if (sliding_window > 0) wg_begin = max(0, (q_base - sliding_window + 1) / kPfStage * kPfStage);
 
-  for (int k0 = k_begin; k0 < k_end; k0 += kPfKeys) {
-    // ---- V tile -> registers (issued first; written to LDS after the Q.K product)
-    uint4 vreg[VLOADS];
+  uint4 kreg[LOADS], vreg[LOADS];
+  auto fetch = [&](int t0) {
 #pragma unroll
-    for (int it = 0; it < VLOADS; ++it) {
-      const int c = it * 64 + lane;
+    for (int it = 0; it < LOADS; ++it) {
+      const int c = it * kPfWaves * 64 + tid;
+      if (CHUNKS % (kPfWaves * 64) != 0 && c >= CHUNKS) continue;
       const int key = c / CPR, ch = c - key * CPR;
-      const int kr = min(k0 + key, seq_len - 1);
-      vreg[it] = *reinterpret_cast<const uint4*>(v + (row0 + kr) * v_stride + (int64_t)kv_head * HEAD + ch * 8);
+      const int64_t row = row0 + min(t0 + key, seq_len - 1);
+      kreg[it] = *reinterpret_cast<const uint4*>(k + row * k_stride + (int64_t)kv_head * HEAD + ch * 8);
+      vreg[it] = *reinterpret_cast<const uint4*>(v + row * v_stride + (int64_t)kv_head * HEAD + ch * 8);
     }
-    // ---- S^T = K . Q^T : A operand = K[key][16*ks + 8*half + j]
-    f32x16 s;
+  };
+  auto commit = [&](int buf) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) s[r] = 0.f;
-    {
-      const int kr = min(k0 + col, seq_len - 1);
-      const uint16_t* kp = k + (row0 + kr) * k_stride + (int64_t)kv_head * HEAD + 8 * half;
-      frag kf[KS];
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) kf[ks] = *reinterpret_cast<const frag*>(kp + 16 * ks);
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) s = M::run(kf[ks], qf[ks], s);
-    }
-    // ---- V registers -> row-major LDS image (wave-private)
-#pragma unroll
-    for (int it = 0; it < VLOADS; ++it) {
-      const int c = it * 64 + lane;
+    for (int it = 0; it < LOADS; ++it) {
+      const int c = it * kPfWaves * 64 + tid;
+      if (CHUNKS % (kPfWaves * 64) != 0 && c >= CHUNKS) continue;
       const int key = c / CPR, ch = c - key * CPR;
-      *reinterpret_cast<uint4*>(v_lds + key * VSTRIDE + ch * 16) = vreg[it];
+      *reinterpret_cast<uint4*>(k_img + (buf * kPfStage + key) * KSTRIDE + ch * 16) = kreg[it];
+      *reinterpret_cast<uint4*>(v_img + (buf * kPfStage + key) * VSTRIDE + ch * 16) = vreg[it];
     }
+  };
 
-    // ---- mask, online softmax (this lane: query q_idx, keys k0 + (r&3) + 8*(r>>2) + 4*half)
-    const bool need_mask = (k0 + kPfKeys - 1 > q0) || (sliding_window > 0);
+  fetch(wg_begin);
+  commit(0);
+  __syncthreads();
+  int buf = 0;
+  for (int t0 = wg_begin; t0 < wg_end; t0 += kPfStage, buf ^= 1) {
+    const bool more = t0 + kPfStage < wg_end;
+    if (more) fetch(t0 + kPfStage);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      float x = s[r] * scale;
-      if (slope != 0.f) x += slope * (float)(key - q_idx);
-      if (need_mask) {
-        bool ok = key <= q_idx;
-        if (sliding_window > 0) ok = ok && (q_idx - key < sliding_window);
-        x = ok ? x : -INFINITY;
+    for (int sub = 0; sub < kPfStage / kPfKeys; ++sub) {
+      const int k0 = t0 + sub * kPfKeys;
+      if (!active || k0 >= k_end || k0 + kPfKeys <= k_begin) continue;      // wave-uniform
+      // ---- S^T = K . Q^T : A operand = K[key][16*ks + 8*half + j]
+      f32x16 s;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = 0.f;
+      {
+        const char* kb = k_img + (buf * kPfStage + sub * kPfKeys) * KSTRIDE + k_off;
+        frag kf[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) kf[ks] = *reinterpret_cast<const frag*>(kb + 32 * ks);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) s = M::run(kf[ks], qf[ks], s);
       }
-      s[r] = x;
-    }
-    softmax_step(s);
-
-    // ---- O^T += V^T . P^T ; A operand element j <-> key 16*st + 8*(j>>2) + 4*half + (j&3)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      // ---- mask, online softmax (this lane: query q_idx, keys k0 + (r&3) + 8*(r>>2) + 4*half)
+      const bool need_mask = (k0 + kPfKeys - 1 > q0) || (sliding_window > 0);
+      if (!need_mask && slope == 0.f) {                            // wave-uniform: a tile below the diagonal
 #pragma unroll
-    for (int st = 0; st < 2; ++st) {
+        for (int r = 0; r < 16; ++r) s[r] *= scale2;
+      } else {
 #pragma unroll
-      for (int b = 0; b < DB; ++b) {
-        const char* base = v_lds + tr_off + (16 * st) * VSTRIDE + b * 64;
-        const i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_i16x4_ptr)(base));
-        const i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_i16x4_ptr)(base + 8 * VSTRIDE));
-        union { struct { i16x4 a, b; } p; frag f; } vf;
-        vf.p.a = lo;
-        vf.p.b = hi;
-        o[b] = M::run(vf.f, pf[st], o[b]);
+        for (int r = 0; r < 16; ++r) {
+          const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          float x = s[r] * scale2;
+          if (slope != 0.f) x += slope2 * (float)(key - q_idx);
+          if (need_mask) {
+            bool ok = key <= q_idx;
+            if (sliding_window > 0) ok = ok && (q_idx - key < sliding_window);
+            x = ok ? x : -INFINITY;
+          }
+          s[r] = x;
+        }
+      }
+      softmax_step(s);
+      // ---- O^T += V^T . P^T ; A operand element j <-> key 16*st + 8*(j>>2) + 4*half + (j&3)
+      const char* vb = v_img + (buf * kPfStage + sub * kPfKeys) * VSTRIDE + tr_off;
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {
+#pragma unroll
+        for (int b = 0; b < DB; ++b) {
+          const char* base = vb + (16 * st) * VSTRIDE + b * 64;
+          const i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_i16x4_ptr)(base));
+          const i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_i16x4_ptr)(base + 8 * VSTRIDE));
+          union { struct { i16x4 a, b; } p; frag f; } vf;
+          vf.p.a = lo;
+          vf.p.b = hi;
+          o[b] = M::run(vf.f, pf[st], o[b]);
+        }
       }
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // the image is rewritten next tile
+    if (more) commit(buf ^ 1);                        // that buffer was last read before the previous barrier
+    __syncthreads();
   }
+  if (!active) return;
 
   // ---- normalise and store: this lane holds query q_idx, O^T rows d = 32*b + (r&3) + 8*(r>>2) + 4*half
   const float l_tot = l_part + __shfl_xor(l_part, 32, 64);
@@ -329,8 +388,12 @@ int launch_prefill(void* out, const void* q, const void* k, const void* v, const
                    int64_t out_stride, int sliding_window, const PfContext& cx, hipStream_t stream) {
   const int rows_per_wg = kPfWaves * kPfRows;
   dim3 grid((max_seq_len + rows_per_wg - 1) / rows_per_wg, num_heads, num_seqs);
-  const size_t smem = (size_t)kPfWaves * kPfKeys * pf_vstride(HEAD);
-  prefill_attention_kernel<act_t, HEAD, CTX><<<grid, kPfWaves * 64, smem, stream>>>(
+  const size_t smem = (size_t)pf_lds_bytes(HEAD);
+  auto kern = prefill_attention_kernel<act_t, HEAD, CTX>;
+  if (smem > 64 * 1024)
+    SW_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)smem));
+  kern<<<grid, kPfWaves * 64, smem, stream>>>(
       static_cast<uint16_t*>(out), static_cast<const uint16_t*>(q), static_cast<const uint16_t*>(k),
       static_cast<const uint16_t*>(v), seq_starts, seq_lens, num_heads, num_kv_heads, scale, alibi, q_stride,
       k_stride, v_stride, out_stride, sliding_window, cx);
