@@ -138,8 +138,9 @@ def test_tensor_parallel_pools_match_cpu_model(split, monkeypatch):
             assert row[tok] >= row.max() - 3e-2, (j, tok, int(row.argmax()), float(row.max() - row[tok]))
 
 
-def test_int4_fp8_cache_split_pools_match_cpu_model(monkeypatch):
-    """The quantised configuration in miniature: GPTQ int4 weights, fp8-e5m2 KV cache, a prompt
+@pytest.mark.parametrize("quantization", ["gptq", "awq"])
+def test_int4_fp8_cache_split_pools_match_cpu_model(quantization, monkeypatch):
+    """The quantised configuration in miniature: int4 weights (GPTQ, AWQ), fp8-e5m2 KV cache, a prompt
     pool and a token pool of two tensor-parallel ranks each.  Judged by the CPU model on the
     reconstructed full fp16 weights, with keys and values of decode steps passed through e5m2."""
     from splitwise_amd import LLM, SamplingParams
@@ -147,7 +148,7 @@ def test_int4_fp8_cache_split_pools_match_cpu_model(monkeypatch):
     from splitwise_amd.model_executor.model_loader import get_model
     monkeypatch.setenv("SPLITWISE_TP_BACKEND", "gloo")
     random.seed(4)
-    llm = LLM("llama-tiny", quantization="gptq", kv_cache_dtype="fp8_e5m2", tensor_parallel_size=2,
+    llm = LLM("llama-tiny", quantization=quantization, kv_cache_dtype="fp8_e5m2", tensor_parallel_size=2,
               sep_prompt_token=True, num_gpu_blocks_override=128, max_num_seqs=8, max_model_len=512, swap_space=0.01)
     try:
         vocab = llm.llm_engine.model_config.get_vocab_size()
@@ -158,8 +159,8 @@ def test_int4_fp8_cache_split_pools_match_cpu_model(monkeypatch):
         llm.llm_engine.model_executor.shutdown()
         del llm
         torch.cuda.empty_cache()
-    full = get_model(ModelConfig("llama-tiny", quantization="gptq"), torch.device("cuda"))
-    sd = _dense_state_dict({k: v.detach().cpu() for k, v in full.state_dict().items()}, "gptq", shuffled=False)
+    full = get_model(ModelConfig("llama-tiny", quantization=quantization), torch.device("cuda"))
+    sd = _dense_state_dict({k: v.detach().cpu() for k, v in full.state_dict().items()}, quantization, shuffled=False)
     for prompt, out in zip(prompts, outs):
         gen = out.outputs[0].token_ids
         assert len(gen) == 12
