@@ -16,4 +16,5 @@ def bench(lens, h=32, kvh=32, d=128, dtype=torch.bfloat16):
     t = timeit(lambda: _C.ops.prefill_attention(out, q, k, v, st, ln, max(lens), s), iters=50)
     flops = sum(4.0 * L * L * h * d / 2 for L in lens)
     print(f"prefill_attention lens={lens[0]}x{len(lens)} H={h} KVH={kvh} D={d}: {t*1e6:8.1f} us  {flops/t/1e12:7.1f} TFLOP/s (causal flops)")
-bench([772] * 3); bench([772]); bench([2048]); bench([512] * 8); bench([4096]); bench([2048], 64, 8); bench([1024] * 2, 40, 40)
+if __name__ == "__main__":
+    bench([772] * 3); bench([772]); bench([2048]); bench([512] * 8); bench([4096]); bench([2048], 64, 8); bench([1024] * 2, 40, 40)

@@ -8,12 +8,27 @@
 #include <stdarg.h>
 #include <stdio.h>
 
+#include <type_traits>
+#include <utility>
+
 #include "../../include/splitwise_hip.h"
 
 namespace sw {
 
 // ---------------------------------------------------------------- host errors
 void set_error(const char* fmt, ...);
+
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>): loops whose index must be a
+// compile-time constant (register arrays)
+template <int... I, typename F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F&& f) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(std::make_integer_sequence<int, N>{}, f);
+}
+
 
 #define SW_CHECK_ARG(cond, ...)                 \
   do {                                          \

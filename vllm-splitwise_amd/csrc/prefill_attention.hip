@@ -64,8 +64,9 @@ __host__ __device__ constexpr int pf_vstride(int head) {          // bytes per V
 __host__ __device__ constexpr int pf_kstride(int head) {          // bytes per K row in LDS: 16 rows on 64 distinct banks
   return head * 2 + 16;
 }
-__host__ __device__ constexpr int pf_lds_bytes(int head) {        // two stages of a K and a V image
-  return 2 * kPfStage * (pf_kstride(head) + pf_vstride(head));
+constexpr int kPfBufs = 3;                           // LDS stages: one in use, one landing, one free
+__host__ __device__ constexpr int pf_lds_bytes(int head) {        // kPfBufs stages of a K and a V image
+  return kPfBufs * kPfStage * (pf_kstride(head) + pf_vstride(head));
 }
 
 // Keys and values that are already in the paged cache (a shared prefix, or the earlier chunks of
@@ -104,8 +105,8 @@ prefill_attention_kernel(uint16_t* __restrict__ out, const uint16_t* __restrict_
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  char* k_img = smem;                                // [2][kPfStage][KSTRIDE]
-  char* v_img = smem + 2 * kPfStage * KSTRIDE;       // [2][kPfStage][VSTRIDE]
+  char* k_img = smem;                                // [kPfBufs][kPfStage][KSTRIDE]
+  char* v_img = smem + kPfBufs * kPfStage * KSTRIDE; // [kPfBufs][kPfStage][VSTRIDE]
 
   const int seq = blockIdx.z;
   const int head = blockIdx.y;
@@ -134,7 +135,7 @@ prefill_attention_kernel(uint16_t* __restrict__ out, const uint16_t* __restrict_
 
   // zero the V images once: pad columns HEAD..DP-1 must read as 0 (never written again)
   if constexpr (DP != HEAD) {
-    for (int i = tid; i < 2 * kPfStage * VSTRIDE / 16; i += kPfWaves * 64)
+    for (int i = tid; i < kPfBufs * kPfStage * VSTRIDE / 16; i += kPfWaves * 64)
       reinterpret_cast<uint4*>(v_img)[i] = make_uint4(0, 0, 0, 0);
     __syncthreads();
   }
@@ -272,36 +273,47 @@ prefill_attention_kernel(uint16_t* __restrict__ out, const uint16_t* __restrict_
   int wg_begin = 0;
   if (sliding_window > 0) wg_begin = max(0, (q_base - sliding_window + 1) / kPfStage * kPfStage);
 
-  uint4 kreg[LOADS], vreg[LOADS];
+  using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
+  // (native vectors: arrays of HIP's uint4 struct, assigned under a condition, are kept in scratch
+  //  memory by the compiler)
+  u32x4 kreg[LOADS], vreg[LOADS];
+  // (compile-time slot indices and no early exit from the loop body: the staging registers must
+  // not end up addressed through memory)
   auto fetch = [&](int t0) {
-#pragma unroll
-    for (int it = 0; it < LOADS; ++it) {
+    static_for<LOADS>([&](auto IT) {
+      constexpr int it = decltype(IT)::value;
       const int c = it * kPfWaves * 64 + tid;
-      if (CHUNKS % (kPfWaves * 64) != 0 && c >= CHUNKS) continue;
-      const int key = c / CPR, ch = c - key * CPR;
-      const int64_t row = row0 + min(t0 + key, seq_len - 1);
-      kreg[it] = *reinterpret_cast<const uint4*>(k + row * k_stride + (int64_t)kv_head * HEAD + ch * 8);
-      vreg[it] = *reinterpret_cast<const uint4*>(v + row * v_stride + (int64_t)kv_head * HEAD + ch * 8);
-    }
+      if (CHUNKS % (kPfWaves * 64) == 0 || c < CHUNKS) {
+        const int key = c / CPR, ch = c - key * CPR;
+        const int64_t row = row0 + min(t0 + key, seq_len - 1);
+        kreg[it] = *reinterpret_cast<const u32x4*>(k + row * k_stride + (int64_t)kv_head * HEAD + ch * 8);
+        vreg[it] = *reinterpret_cast<const u32x4*>(v + row * v_stride + (int64_t)kv_head * HEAD + ch * 8);
+      }
+    });
   };
   auto commit = [&](int buf) {
-#pragma unroll
-    for (int it = 0; it < LOADS; ++it) {
+    static_for<LOADS>([&](auto IT) {
+      constexpr int it = decltype(IT)::value;
       const int c = it * kPfWaves * 64 + tid;
-      if (CHUNKS % (kPfWaves * 64) != 0 && c >= CHUNKS) continue;
-      const int key = c / CPR, ch = c - key * CPR;
-      *reinterpret_cast<uint4*>(k_img + (buf * kPfStage + key) * KSTRIDE + ch * 16) = kreg[it];
-      *reinterpret_cast<uint4*>(v_img + (buf * kPfStage + key) * VSTRIDE + ch * 16) = vreg[it];
-    }
+      if (CHUNKS % (kPfWaves * 64) == 0 || c < CHUNKS) {
+        const int key = c / CPR, ch = c - key * CPR;
+        *reinterpret_cast<u32x4*>(k_img + (buf * kPfStage + key) * KSTRIDE + ch * 16) = kreg[it];
+        *reinterpret_cast<u32x4*>(v_img + (buf * kPfStage + key) * VSTRIDE + ch * 16) = vreg[it];
+      }
+    });
   };
 
+  // stage t is computed from LDS buffer t % 3 while stage t+1 (fetched one iteration earlier) is
+  // written to the next buffer and stage t+2 is on its way from global memory in registers
   fetch(wg_begin);
   commit(0);
+  if (wg_begin + kPfStage < wg_end) fetch(wg_begin + kPfStage);
   __syncthreads();
   int buf = 0;
-  for (int t0 = wg_begin; t0 < wg_end; t0 += kPfStage, buf ^= 1) {
-    const bool more = t0 + kPfStage < wg_end;
-    if (more) fetch(t0 + kPfStage);
+  for (int t0 = wg_begin; t0 < wg_end; t0 += kPfStage) {
+    const int nxt = buf == kPfBufs - 1 ? 0 : buf + 1;
+    if (t0 + kPfStage < wg_end) commit(nxt);          // last read two barriers ago
+    if (t0 + 2 * kPfStage < wg_end) fetch(t0 + 2 * kPfStage);
 #pragma unroll
     for (int sub = 0; sub < kPfStage / kPfKeys; ++sub) {
       const int k0 = t0 + sub * kPfKeys;
@@ -354,8 +366,8 @@ prefill_attention_kernel(uint16_t* __restrict__ out, const uint16_t* __restrict_
         }
       }
     }
-    if (more) commit(buf ^ 1);                        // that buffer was last read before the previous barrier
     __syncthreads();
+    buf = nxt;
   }
   if (!active) return;
 
@@ -390,6 +402,7 @@ int launch_prefill(void* out, const void* q, const void* k, const void* v, const
   dim3 grid((max_seq_len + rows_per_wg - 1) / rows_per_wg, num_heads, num_seqs);
   const size_t smem = (size_t)pf_lds_bytes(HEAD);
   auto kern = prefill_attention_kernel<act_t, HEAD, CTX>;
+
   if (smem > 64 * 1024)
     SW_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)smem));

@@ -57,17 +57,6 @@ __device__ __forceinline__ int arrive(int32_t* counter) {
   return __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>): loops whose index must be a
-// compile-time constant (register arrays)
-template <int... I, typename F>
-__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F&& f) {
-  (f(std::integral_constant<int, I>{}), ...);
-}
-template <int N, typename F>
-__device__ __forceinline__ void static_for(F&& f) {
-  static_for_impl(std::make_integer_sequence<int, N>{}, f);
-}
-
 __device__ __forceinline__ h2 as_h2(uint32_t u) { return __builtin_bit_cast(h2, u); }
 __device__ __forceinline__ uint32_t as_u32(h2 v) { return __builtin_bit_cast(uint32_t, v); }
 __device__ __forceinline__ h2 splat(_Float16 v) { return h2{v, v}; }
@@ -403,24 +392,29 @@ gptq_gemm_tiled_kernel(uint16_t* __restrict__ c, const uint16_t* __restrict__ a,
       for (int r = 0; r < 16; ++r) acc[t][cc][r] = 0.f;
 
   // ---- A staging: piece p = (row, 16-byte segment)
-  uint4 a_stage[PPT];
+  u32x4 a_stage[PPT];                                 // (a native vector: arrays of HIP's uint4 struct, assigned
+                                                      //  under a condition, are kept in scratch memory by the compiler)
+  // (compile-time slot indices and no early exit from the loop body: the staging registers must
+  // not end up addressed through memory)
   auto a_fetch = [&](int chunk) {
-#pragma unroll
-    for (int q = 0; q < PPT; ++q) {
-      const int p = tid + q * kGemmWaves * 64;
-      if (PIECES % (kGemmWaves * 64) != 0 && p >= PIECES) continue;
-      const int row = p / SEGS, seg = p % SEGS;
-      a_stage[q] = *reinterpret_cast<const uint4*>(a + (size_t)min(m0 + row, M - 1) * K + chunk * kChunkK + seg * 8);
-    }
+    static_for<PPT>([&](auto Q) {
+      constexpr int qi = decltype(Q)::value;
+      const int p = tid + qi * kGemmWaves * 64;
+      if (PIECES % (kGemmWaves * 64) == 0 || p < PIECES) {
+        const int row = p / SEGS, seg = p % SEGS;
+        a_stage[qi] = *reinterpret_cast<const u32x4*>(a + (size_t)min(m0 + row, M - 1) * K + chunk * kChunkK + seg * 8);
+      }
+    });
   };
   auto a_commit = [&](int buf) {
-#pragma unroll
-    for (int q = 0; q < PPT; ++q) {
-      const int p = tid + q * kGemmWaves * 64;
-      if (PIECES % (kGemmWaves * 64) != 0 && p >= PIECES) continue;
-      const int row = p / SEGS, seg = p % SEGS;
-      *reinterpret_cast<uint4*>(a_lds + buf * BM * kARow + row * kARow + seg * 16) = a_stage[q];
-    }
+    static_for<PPT>([&](auto Q) {
+      constexpr int qi = decltype(Q)::value;
+      const int p = tid + qi * kGemmWaves * 64;
+      if (PIECES % (kGemmWaves * 64) == 0 || p < PIECES) {
+        const int row = p / SEGS, seg = p % SEGS;
+        *reinterpret_cast<u32x4*>(a_lds + buf * BM * kARow + row * kARow + seg * 16) = a_stage[qi];
+      }
+    });
   };
 
   // ---- weight ring (as in gptq_stream)
