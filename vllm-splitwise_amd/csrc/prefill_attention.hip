@@ -81,7 +81,7 @@ struct PfContext {
 };
 
 template <typename act_t, int HEAD, bool CTX>
-__global__ void __launch_bounds__(kPfWaves * 64)
+__global__ void __launch_bounds__(kPfWaves * 64, HEAD <= 128 && !CTX ? 2 : 1)
 prefill_attention_kernel(uint16_t* __restrict__ out, const uint16_t* __restrict__ q,
                          const uint16_t* __restrict__ k, const uint16_t* __restrict__ v,
                          const int32_t* __restrict__ seq_starts, const int32_t* __restrict__ seq_lens,
@@ -303,33 +303,55 @@ prefill_attention_kernel(uint16_t* __restrict__ out, const uint16_t* __restrict_
     });
   };
 
-  // stage t is computed from LDS buffer t % 3 while stage t+1 (fetched one iteration earlier) is
-  // written to the next buffer and stage t+2 is on its way from global memory in registers
+  // Software pipeline over stages (one stage = one score tile of 32 keys), three LDS buffers:
+  //   iteration t:  stage t+2 registers -> LDS | stage t+3 global -> registers |
+  //                 S(t+1) = K(t+1) . Q^T on the matrix cores, issued BEFORE the vector work of
+  //                 softmax(S(t)), so the two overlap inside the wave | O += V(t)^T . P(t)^T | barrier
+  static_assert(kPfStage == kPfKeys, "one score tile per stage");
+  const int stages = (wg_end - wg_begin + kPfStage - 1) / kPfStage;
+  auto needs = [&](int t) {
+    const int k0 = wg_begin + t * kPfStage;
+    return active && k0 < k_end && k0 + kPfKeys > k_begin;
+  };
+  auto qk = [&](int buf) {
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const char* kb = k_img + buf * kPfStage * KSTRIDE + k_off;
+#pragma unroll
+    for (int h0 = 0; h0 < KS; h0 += 4) {              // fragments in groups of 4: fewer live registers
+      frag kf[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (h0 + i < KS) kf[i] = *reinterpret_cast<const frag*>(kb + 32 * (h0 + i));
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (h0 + i < KS) acc = M::run(kf[i], qf[h0 + i], acc);
+    }
+    return acc;
+  };
+
   fetch(wg_begin);
   commit(0);
-  if (wg_begin + kPfStage < wg_end) fetch(wg_begin + kPfStage);
+  if (stages > 1) {
+    fetch(wg_begin + kPfStage);
+    commit(1);
+  }
+  if (stages > 2) fetch(wg_begin + 2 * kPfStage);
   __syncthreads();
+  f32x16 s_cur, s_next;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) s_cur[r] = s_next[r] = 0.f;
+  if (needs(0)) s_cur = qk(0);
   int buf = 0;
-  for (int t0 = wg_begin; t0 < wg_end; t0 += kPfStage) {
-    const int nxt = buf == kPfBufs - 1 ? 0 : buf + 1;
-    if (t0 + kPfStage < wg_end) commit(nxt);          // last read two barriers ago
-    if (t0 + 2 * kPfStage < wg_end) fetch(t0 + 2 * kPfStage);
-#pragma unroll
-    for (int sub = 0; sub < kPfStage / kPfKeys; ++sub) {
-      const int k0 = t0 + sub * kPfKeys;
-      if (!active || k0 >= k_end || k0 + kPfKeys <= k_begin) continue;      // wave-uniform
-      // ---- S^T = K . Q^T : A operand = K[key][16*ks + 8*half + j]
-      f32x16 s;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) s[r] = 0.f;
-      {
-        const char* kb = k_img + (buf * kPfStage + sub * kPfKeys) * KSTRIDE + k_off;
-        frag kf[KS];
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) kf[ks] = *reinterpret_cast<const frag*>(kb + 32 * ks);
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) s = M::run(kf[ks], qf[ks], s);
-      }
+  for (int t = 0; t < stages; ++t) {
+    const int k0 = wg_begin + t * kPfStage;
+    const int b1 = buf == 2 ? 0 : buf + 1, b2 = b1 == 2 ? 0 : b1 + 1;
+    if (t + 2 < stages) commit(b2);                   // that buffer was last read before the previous barrier
+    if (t + 3 < stages) fetch(k0 + 3 * kPfStage);
+    if (t + 1 < stages && needs(t + 1)) s_next = qk(b1);
+    if (needs(t)) {
+      f32x16& s = s_cur;
       // ---- mask, online softmax (this lane: query q_idx, keys k0 + (r&3) + 8*(r>>2) + 4*half)
       const bool need_mask = (k0 + kPfKeys - 1 > q0) || (sliding_window > 0);
       if (!need_mask && slope == 0.f) {                            // wave-uniform: a tile below the diagonal
@@ -351,7 +373,7 @@ prefill_attention_kernel(uint16_t* __restrict__ out, const uint16_t* __restrict_
       }
       softmax_step(s);
       // ---- O^T += V^T . P^T ; A operand element j <-> key 16*st + 8*(j>>2) + 4*half + (j&3)
-      const char* vb = v_img + (buf * kPfStage + sub * kPfKeys) * VSTRIDE + tr_off;
+      const char* vb = v_img + buf * kPfStage * VSTRIDE + tr_off;
 #pragma unroll
       for (int st = 0; st < 2; ++st) {
 #pragma unroll
@@ -367,7 +389,8 @@ prefill_attention_kernel(uint16_t* __restrict__ out, const uint16_t* __restrict_
       }
     }
     __syncthreads();
-    buf = nxt;
+    s_cur = s_next;
+    buf = b1;
   }
   if (!active) return;
 
