@@ -941,7 +941,7 @@ int sw_gptq_gemm(void* c, const void* a, const uint32_t* qweight, const uint32_t
   if (const char* env = getenv("SW_QUANT_MT")) mt = atoi(env);
   if (const char* env = getenv("SW_QUANT_TILED")) tiled = atoi(env) != 0 && K % kChunkK == 0;
   if (mt == 3 || mt > 4) mt = 4;
-  if (tiled && mt > 2) mt = 2;
+  if (tiled && mt > 2) mt = 2;                        // 128-row tiles spill in the tiled kernel
   const int row_tiles = (M + 32 * mt - 1) / (32 * mt);
   if (tiled) {
     const int tile_cols = 32 * cp * kGemmWaves;
@@ -950,8 +950,14 @@ int sw_gptq_gemm(void* c, const void* a, const uint32_t* qweight, const uint32_t
     const dim3 grid(col_tiles, row_tiles, ks);
     const size_t lds = (size_t)2 * 32 * mt * kARow;
 #define SW_GPTQ_TILED(MT_, CP_)                                                                                 \
-  hipLaunchKernelGGL((gptq_gemm_tiled_kernel<MT_, CP_>), grid, dim3(kGemmWaves * 64), lds, st, out, ap, qweight, \
-                     qzeros, sp, M, N, K, group_size, ks, partials, counters)
+  do {                                                                                                          \
+    auto kern = gptq_gemm_tiled_kernel<MT_, CP_>;                                                               \
+    if (lds > 64 * 1024)                                                                                        \
+      SW_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                     \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                  \
+    hipLaunchKernelGGL(kern, grid, dim3(kGemmWaves * 64), lds, st, out, ap, qweight, qzeros, sp, M, N, K,       \
+                       group_size, ks, partials, counters);                                                     \
+  } while (0)
     if (mt == 1 && cp == 2) SW_GPTQ_TILED(1, 2);
     else if (mt == 1) SW_GPTQ_TILED(1, 4);
     else if (mt == 2 && cp == 2) SW_GPTQ_TILED(2, 2);
