@@ -95,3 +95,29 @@ def test_slab_layout_is_symmetric_and_avoids_the_unmappable_sizes():
         n = _ipc_safe_size(int(gib * 2 ** 30))
         assert n >= int(gib * 2 ** 30) and n % 2 ** 32 < 2 ** 31
     assert _ipc_safe_size(1 << 30) == 1 << 30
+
+
+def test_decode_commands_travel_without_token_ids():
+    """What crosses the control channel for a decode step: (length, last token) per sequence and
+    compact sample tuples back; prompt steps keep every token."""
+    import pickle
+    from splitwise_amd.sampling_params import SamplingParams
+    from splitwise_amd.sequence import (Logprob, SamplerOutput, SequenceData, SequenceGroupMetadata,
+                                        SequenceGroupOutput, SequenceOutput, pack_sampler_output,
+                                        slim_decode_metadata, unpack_sampler_output)
+    sp = SamplingParams(temperature=0.0, max_tokens=4)
+    data = SequenceData(list(range(700)), [5, 6, 7])
+    decode = [SequenceGroupMetadata("a", False, {3: data}, sp, {3: [9, 4]})]
+    slim = slim_decode_metadata(decode)
+    d = slim[0].seq_data[3]
+    assert (d.get_len(), d.get_last_token_id()) == (703, 7) and slim[0].block_tables == {3: [9, 4]}
+    assert not slim[0].is_prompt and slim[0].request_id == "a" and slim[0].sampling_params is sp
+    assert len(pickle.dumps(slim)) < len(pickle.dumps(decode)) // 3
+    with pytest.raises(RuntimeError):
+        d.get_token_ids()
+    prompt = [SequenceGroupMetadata("b", True, {4: data}, sp, {4: [1]})]
+    assert slim_decode_metadata(prompt) is prompt
+    out = SamplerOutput([SequenceGroupOutput([SequenceOutput(3, 11, {11: Logprob(-0.25)})], None),
+                         SequenceGroupOutput([SequenceOutput(8, 2, {2: Logprob(0.0)})], None)])
+    back = unpack_sampler_output(pickle.loads(pickle.dumps(pack_sampler_output(out))))
+    assert [g.samples[0] for g in back] == [g.samples[0] for g in out]

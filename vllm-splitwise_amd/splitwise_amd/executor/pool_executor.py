@@ -20,7 +20,7 @@ from typing import Any, Dict, List, Optional, Sequence, Tuple
 import torch
 
 from ..config import CacheConfig, DeviceConfig, ModelConfig, ParallelConfig, SchedulerConfig
-from ..sequence import SamplerOutput, SequenceGroupMetadata
+from ..sequence import SamplerOutput, SequenceGroupMetadata, slim_decode_metadata, unpack_sampler_output
 from ..worker.worker import Worker
 from .channel import PipeChannel
 from .executor_base import ExecutorBase
@@ -87,10 +87,17 @@ class PoolExecutor(ExecutorBase):
 
     # ------------------------------------------------------------ control plane
     def _send(self, rank: int, name: str, kwargs: dict) -> None:
-        self.channels[rank].send(("execute", kwargs) if name == "execute_model" else ("call", name, kwargs))
+        if name == "execute_model":
+            # decode commands travel without the sequences' token ids
+            slim = slim_decode_metadata(kwargs["seq_group_metadata_list"])
+            self.channels[rank].send(("execute", dict(kwargs, seq_group_metadata_list=slim)))
+        else:
+            self.channels[rank].send(("call", name, kwargs))
 
     def _wait(self, rank: int):
         status, result = self.channels[rank].recv()
+        if status == "samples":
+            return unpack_sampler_output(result)
         if status != "ok":
             raise RuntimeError(f"worker {rank} failed: {result}")
         return result

@@ -5,6 +5,7 @@ from typing import Any, Dict
 import torch
 
 from ..config import DeviceConfig
+from ..sequence import SamplerOutput, pack_sampler_output
 from ..worker.worker import Worker
 
 
@@ -49,6 +50,9 @@ def worker_loop(channel, cfg: Dict[str, Any], worker_cls=Worker) -> None:
                     result = worker.execute_model(**kwargs)
                     if not reports:
                         result = None
+                    elif isinstance(result, SamplerOutput):
+                        channel.send(("samples", pack_sampler_output(result)))
+                        continue
                 elif cmd == "bytes_pushed":
                     comm = worker.kvcache_comm_manager.kvcache_comm if worker.kvcache_comm_manager else None
                     result = comm.bytes_pushed if comm else 0

@@ -15,6 +15,7 @@ import torch
 
 from ..config import CacheConfig, DeviceConfig, ModelConfig, ParallelConfig, SchedulerConfig
 from ..sequence import SamplerOutput, SequenceGroupMetadata
+from ..sequence import slim_decode_metadata, unpack_sampler_output
 from ..worker.worker import Worker
 from .channel import PipeChannel
 from .executor_base import ExecutorBase
@@ -84,6 +85,8 @@ class SplitwiseExecutor(ExecutorBase):
 
     def _remote_wait(self):
         status, result = self.channel.recv()
+        if status == "samples":
+            return unpack_sampler_output(result)
         if status != "ok":
             raise RuntimeError(f"token worker failed: {result}")
         return result
@@ -135,14 +138,15 @@ class SplitwiseExecutor(ExecutorBase):
             return SamplerOutput([])
         if seq_group_metadata_list[0].is_prompt:
             return self.driver_worker.execute_model(**kwargs)
-        self.channel.send(("execute", kwargs))
+        self.channel.send(("execute", dict(kwargs, seq_group_metadata_list=slim_decode_metadata(seq_group_metadata_list))))
         return self._remote_wait()
 
     def execute_split(self, prompt_kwargs: Optional[dict], decode_kwargs: Optional[dict]):
         """Runs a prompt step here and a decode step on the token GPU concurrently.
         -> (prompt SamplerOutput or None, decode SamplerOutput or None)"""
         if decode_kwargs is not None:
-            self.channel.send(("execute", decode_kwargs))
+            slim = slim_decode_metadata(decode_kwargs["seq_group_metadata_list"])
+            self.channel.send(("execute", dict(decode_kwargs, seq_group_metadata_list=slim)))
         prompt_out = self.driver_worker.execute_model(**prompt_kwargs) if prompt_kwargs is not None else None
         decode_out = self._remote_wait() if decode_kwargs is not None else None
         return prompt_out, decode_out

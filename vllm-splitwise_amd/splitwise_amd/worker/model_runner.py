@@ -72,6 +72,7 @@ class ModelRunner:
         self.enforce_eager = model_config.enforce_eager if model_config is not None else True
         # samples of the previous step that were left on the device (pipelined engine steps)
         self.pending: Optional[PendingSamples] = None
+        self._generators: Dict[str, torch.Generator] = {}
 
     # ------------------------------------------------------------------ set-up
     def load_model(self) -> None:
@@ -243,7 +244,15 @@ class ModelRunner:
                 n_rows = len(seq_ids)
             if params.seed is not None:
                 if meta.state.generator is None:
-                    meta.state.generator = torch.Generator(device=self.device).manual_seed(params.seed)
+                    # the state object of a command that crossed a process boundary is a fresh copy:
+                    # the request's generator is kept here, by request id
+                    gen = self._generators.get(meta.request_id)
+                    if gen is None or meta.is_prompt:
+                        gen = torch.Generator(device=self.device).manual_seed(params.seed)
+                        if len(self._generators) >= 4096:
+                            self._generators.pop(next(iter(self._generators)))
+                        self._generators[meta.request_id] = gen
+                    meta.state.generator = gen
                 for r in range(len(selected) - n_rows, len(selected)):
                     generators[r] = meta.state.generator
             row += n_rows
