@@ -25,6 +25,22 @@ def next_token(tokens: List[int]) -> int:
     return acc % VOCAB
 
 
+class _Deferred:
+    """Stands for samples that are still on the device."""
+
+    def __init__(self, out: SamplerOutput) -> None:
+        self.out = out
+
+    def done(self) -> bool:
+        return True
+
+    def wait(self) -> None:
+        pass
+
+    def resolve(self) -> SamplerOutput:
+        return self.out
+
+
 class _FakeComm:
     def __init__(self) -> None:
         self.bytes_pushed = 0
@@ -101,7 +117,14 @@ class FakeWorker:
         return [int(self.cache[block_table[i // self.block_size], i % self.block_size]) for i in range(n)]
 
     def execute_model(self, seq_group_metadata_list=None, blocks_to_swap_in=None, blocks_to_swap_out=None,
-                      blocks_to_copy=None, blocks_to_nw=None, nw_epochs=None) -> SamplerOutput:
+                      blocks_to_copy=None, blocks_to_nw=None, nw_epochs=None, defer=False):
+        out = self._execute(seq_group_metadata_list, blocks_to_nw, nw_epochs)
+        # like the device, this worker remembers the tokens it sampled last: a deferred step's tokens
+        # reach the engine one call later, and the next command names them by a placeholder (-1)
+        self._last_samples = {g.samples[0].parent_seq_id: g.samples[0].output_token for g in out}
+        return _Deferred(out) if defer else out
+
+    def _execute(self, seq_group_metadata_list, blocks_to_nw, nw_epochs) -> SamplerOutput:
         blocks_to_nw = blocks_to_nw or {}
         outputs = []
         if self.is_prompt:
@@ -137,6 +160,8 @@ class FakeWorker:
             # the cache holds (pushed by the prompt side, then written step by step here), so a lost or
             # misplaced block shows up as a wrong token
             n, last = data.get_len(), data.get_last_token_id()
+            if last == -1:
+                last = self._last_samples[seq_id]
             table = meta.block_tables[seq_id]
             self._write(table, n - 1, last)                          # this step's own KV entry
             cached = self._read(table, n)

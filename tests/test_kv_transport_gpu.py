@@ -104,16 +104,17 @@ def test_transport_self_test_between_two_processes(transport, blocks, kv_dtype):
         ex.shutdown()
 
 
-@pytest.mark.parametrize("overlap", [True, False])
+@pytest.mark.parametrize("overlap", [True, False, "pipelined"])
 def test_split_engine_generates_like_the_cpu_model(overlap):
     """1 prompt worker + 1 token worker (two processes): every decode step runs on KV that was
     pushed from the prompt worker; greedy tokens must agree with the whole-model CPU oracle."""
     from splitwise_amd import SamplingParams
     from oracle import model as omodel
     random.seed(0)
-    llm = _split_llm("kernel")
+    llm = _split_llm("kernel", pipeline_steps=overlap == "pipelined")
     try:
-        llm.llm_engine.overlap_pools = overlap
+        assert llm.llm_engine.pipeline_split == (overlap == "pipelined")
+        llm.llm_engine.overlap_pools = bool(overlap)
         prompts = [[random.randrange(512) for _ in range(n)] for n in (5, 33, 64, 17, 100, 1, 16, 48, 7, 90, 31)]
         outs = llm.generate(prompt_token_ids=prompts, sampling_params=SamplingParams(temperature=0.0, max_tokens=20))
         assert all(len(o.outputs[0].token_ids) == 20 for o in outs)

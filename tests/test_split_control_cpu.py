@@ -18,7 +18,7 @@ def _free_port() -> int:
         return s.getsockname()[1]
 
 
-def _rank_main(rank: int, port: int, tmpdir: str, result_path: str, blocks: int) -> None:
+def _rank_main(rank: int, port: int, tmpdir: str, result_path: str, blocks: int, pipeline: bool) -> None:
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     sys.path.insert(0, here)
@@ -33,7 +33,7 @@ def _rank_main(rank: int, port: int, tmpdir: str, result_path: str, blocks: int)
     from splitwise_amd.executor.splitwise_executor import SplitwiseExecutor
 
     args = EngineArgs(model="llama-tiny", sep_prompt_token=True, max_num_seqs=6, max_model_len=128,
-                      max_num_batched_tokens=512, swap_space=0.001)
+                      max_num_batched_tokens=512, swap_space=0.001, pipeline_steps=pipeline)
     mc, cc, pc, sc, dc = args.create_engine_configs()
     if rank == 1:
         cfg = {"model_config": mc, "parallel_config": pc, "scheduler_config": sc, "cache_config": cc, "rank": 1,
@@ -44,6 +44,7 @@ def _rank_main(rank: int, port: int, tmpdir: str, result_path: str, blocks: int)
     executor = SplitwiseExecutor(mc, cc, pc, sc, dc, channel=DistChannel(1), worker_cls=FakeWorker)
     assert cc.num_gpu_blocks == blocks                           # the smaller of the two pools
     engine = LLMEngine(mc, cc, pc, sc, dc, executor=executor)
+    assert engine.pipeline_split == pipeline
     rng = random.Random(0)
     prompts = {str(i): [rng.randrange(VOCAB) for _ in range(rng.choice([1, 5, 16, 17, 40, 60]))] for i in range(14)}
     lens = {rid: rng.choice([1, 2, 9, 30, 40]) for rid in prompts}
@@ -77,11 +78,12 @@ def _rank_main(rank: int, port: int, tmpdir: str, result_path: str, blocks: int)
     dist.barrier()
 
 
+@pytest.mark.parametrize("pipeline", [False, True])  # True: both pools keep a step in flight (placeholder tokens)
 @pytest.mark.parametrize("blocks", [64, 16])       # 16 blocks: decodes run out of cache, sequences are
-def test_split_engine_over_gloo_world_size_2(blocks):  # preempted, recomputed and handed over again
+def test_split_engine_over_gloo_world_size_2(blocks, pipeline):  # preempted, recomputed and handed over again
     with tempfile.TemporaryDirectory() as tmp:
         result = os.path.join(tmp, "result.txt")
-        mp.spawn(_rank_main, args=(_free_port(), tmp, result, blocks), nprocs=2, join=True)
+        mp.spawn(_rank_main, args=(_free_port(), tmp, result, blocks, pipeline), nprocs=2, join=True)
         assert open(result).read() == "ok"
 
 

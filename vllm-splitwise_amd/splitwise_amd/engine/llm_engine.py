@@ -55,6 +55,11 @@ class LLMEngine:
         self.pipeline_steps = (getattr(scheduler_config, "pipeline_steps", False) and not self.overlap_pools
                                and getattr(self.model_executor, "supports_deferred_samples", False))
         self._inflight = None           # (pending samples, scheduler outputs, [(group, sequence)])
+        # split pools, pipelined: the prompt pool and the token pool each have a step in flight
+        self.pipeline_split = (getattr(scheduler_config, "pipeline_steps", False) and self.overlap_pools
+                               and getattr(self.model_executor, "supports_pipelined_split", False))
+        self._prompt_inflight = None    # (pending samples, scheduler outputs, request ids)
+        self._decode_inflight = None    # (scheduler outputs, [(group, sequence)])
 
     @classmethod
     def from_engine_args(cls, engine_args: EngineArgs, **kwargs) -> "LLMEngine":
@@ -84,7 +89,8 @@ class LLMEngine:
         return self.scheduler.get_num_unfinished_seq_groups()
 
     def has_unfinished_requests(self) -> bool:
-        return self.scheduler.has_unfinished_seqs() or self._inflight is not None
+        return (self.scheduler.has_unfinished_seqs() or self._inflight is not None
+                or self._prompt_inflight is not None or self._decode_inflight is not None)
 
     # --------------------------------------------------------------------- step
     def _check_stop(self, seq: Sequence, params: SamplingParams) -> None:
@@ -159,7 +165,10 @@ class LLMEngine:
     def _resolve_inflight(self) -> List[RequestOutput]:
         pending, scheduler_outputs, pairs = self._inflight
         self._inflight = None
-        output = pending.resolve()
+        return self._apply_deferred(pending.resolve(), scheduler_outputs, pairs)
+
+    def _apply_deferred(self, output: SamplerOutput, scheduler_outputs: SchedulerOutputs, pairs) -> List[RequestOutput]:
+        """Fills in the tokens of a step whose sequences have carried placeholders since its launch."""
         now = time.time()
         reported: List[SequenceGroup] = []
         for (group, seq), out in zip(pairs, output):
@@ -188,6 +197,73 @@ class LLMEngine:
             self.stat_logger.log(self._get_stats(scheduler_outputs, reported, now))
         return [RequestOutput.from_seq_group(g) for g in reported]
 
+    def _launch_bookkeeping(self, pairs) -> None:
+        """After a deferred step has been launched and the previous one resolved: every sequence of
+        the new step gets its placeholder; the ones that end by length are retired at once."""
+        for group, seq in pairs:
+            if seq.is_finished():
+                continue            # a stop token of the previous step ended it; this step's sample is dropped
+            seq.append_placeholder()
+            if self._finished_by_length(seq, group.sampling_params):
+                # device work is stream-ordered, so the blocks can be handed out again at once
+                seq.status = SequenceStatus.FINISHED_LENGTH_CAPPED
+                self.scheduler.free_seq(seq)
+        self.scheduler.free_finished_seq_groups()
+
+    def _step_split_pipelined(self) -> List[RequestOutput]:
+        """Prompt pool and token pool run free of each other: a prompt step is started whenever the
+        prompt pool is idle and collected when it has finished; every call starts the next decode
+        step and collects the previous one, so the token GPU always has a step queued."""
+        ex = self.model_executor
+        outputs: List[RequestOutput] = []
+        progressed = False
+        # ---- prompt pool
+        if self._prompt_inflight is not None and self._prompt_inflight[0].done():
+            pending, outs_p, ids = self._prompt_inflight
+            self._prompt_inflight = None
+            sampled = pending.resolve()
+            live = [(g, o) for g, o in zip(outs_p.scheduled_seq_groups, sampled)
+                    if g.get_seqs(status=SequenceStatus.RUNNING)]              # not aborted meanwhile
+            outputs += self._process_model_outputs(SamplerOutput([o for _, o in live]), outs_p,
+                                                   groups=[g for g, _ in live])
+            self.scheduler.prompt_step_done(ids)
+            progressed = True
+        if self._prompt_inflight is None:
+            metas_p, outs_p = self.scheduler.schedule_prompts()
+            if metas_p:
+                for slot in outs_p.blocks_to_nw:
+                    self._slot_epoch[slot] = self._slot_epoch.get(slot, 0) + 1
+                pending = ex.launch_prompt(dict(
+                    seq_group_metadata_list=metas_p, blocks_to_swap_in={}, blocks_to_swap_out={}, blocks_to_copy={},
+                    blocks_to_nw=outs_p.blocks_to_nw, nw_epochs={s: self._slot_epoch[s] for s in outs_p.blocks_to_nw}))
+                outs_p.scheduled_seq_groups = list(outs_p.scheduled_seq_groups)
+                self._prompt_inflight = (pending, outs_p, [m.request_id for m in metas_p])
+                progressed = True
+            else:                                              # (with a launch they are reported when it resolves)
+                outputs += [RequestOutput.from_seq_group(g) for g in outs_p.ignored_seq_groups]
+        # ---- token pool
+        metas_d, outs_d = self.scheduler.schedule_decodes()
+        decode_kwargs, pairs = None, None
+        if metas_d:
+            pairs = [(g, g.get_seqs(status=SequenceStatus.RUNNING)[0]) for g in outs_d.scheduled_seq_groups]
+            decode_kwargs = dict(seq_group_metadata_list=metas_d, blocks_to_swap_in=outs_d.blocks_to_swap_in,
+                                 blocks_to_swap_out=outs_d.blocks_to_swap_out, blocks_to_copy=outs_d.blocks_to_copy,
+                                 blocks_to_nw=outs_d.blocks_to_nw,
+                                 nw_epochs={s: self._slot_epoch.get(s, 0) for s in outs_d.blocks_to_nw})
+        if decode_kwargs is not None or self._decode_inflight is not None:
+            previous = ex.decode_deferred(decode_kwargs)
+            if self._decode_inflight is not None:
+                outs_prev, pairs_prev = self._decode_inflight
+                self._decode_inflight = None
+                outputs += self._apply_deferred(previous, outs_prev, pairs_prev)
+            if pairs is not None:
+                self._launch_bookkeeping(pairs)
+                self._decode_inflight = (outs_d, pairs)
+            progressed = True
+        if not progressed and self._prompt_inflight is not None:
+            self._prompt_inflight[0].wait()                    # nothing else to do: wait for the prompt step
+        return outputs
+
     def _step_pipelined(self) -> List[RequestOutput]:
         metas, scheduler_outputs = self.scheduler.schedule()
         launched = None
@@ -201,15 +277,7 @@ class LLMEngine:
         # the previous step has finished by now (or does so while the new one runs)
         outputs = self._resolve_inflight() if self._inflight is not None else []
         if launched is not None:
-            for group, seq in launched[2]:
-                if seq.is_finished():
-                    continue        # a stop token of the previous step ended it; this step's sample is dropped
-                seq.append_placeholder()
-                if self._finished_by_length(seq, group.sampling_params):
-                    # device work is stream-ordered, so the blocks can be handed out again at once
-                    seq.status = SequenceStatus.FINISHED_LENGTH_CAPPED
-                    self.scheduler.free_seq(seq)
-            self.scheduler.free_finished_seq_groups()
+            self._launch_bookkeeping(launched[2])
             self._inflight = launched
         outputs += [RequestOutput.from_seq_group(g) for g in scheduler_outputs.ignored_seq_groups]
         return outputs
@@ -217,6 +285,8 @@ class LLMEngine:
     def step(self) -> List[RequestOutput]:
         """One scheduling decision, one model step on the executor, outputs appended
         (vllm/engine/llm_engine.py:571-633)."""
+        if self.pipeline_split:
+            return self._step_split_pipelined()
         if self.overlap_pools:
             return self._step_split()
         if self.pipeline_steps:

@@ -84,7 +84,8 @@ def _run(args, rank: int, local_rank: int, world: int) -> None:
                              max_num_batched_tokens=args.max_num_batched_tokens,
                              num_gpu_blocks_override=int(conc * seq_blocks * 1.25) + 64, swap_space=0.25,
                              enforce_eager=args.enforce_eager, max_context_len_to_capture=1024,
-                             prefill_batch_tokens=args.prefill_batch_tokens, prefill_max_wait=args.prefill_max_wait)
+                             prefill_batch_tokens=args.prefill_batch_tokens, prefill_max_wait=args.prefill_max_wait,
+                             pipeline_steps=not getattr(args, "no_pipeline_steps", False))
     mc, cc, pc, sc, dc = engine_args.create_engine_configs()
     transport = os.environ.get("SPLITWISE_KV_TRANSPORT", "kernel")
 
@@ -160,7 +161,8 @@ def _run(args, rank: int, local_rank: int, world: int) -> None:
                                    f"with {conc} requests in flight per pair, prefill {args.prompt_len} / decode "
                                    f"{args.decode_len} tokens, random-init weights, SLO TTFT<={bench_main.SLO_TTFT}s "
                                    f"TPOT<={bench_main.SLO_TPOT}s",
-                       "parallelism": f"{pairs}x(1P+1D)", "concurrency_per_pair": conc},
+                       "parallelism": f"{pairs}x(1P+1D)", "concurrency_per_pair": conc,
+                       "pipeline_steps": bool(engine.pipeline_split)},
             "throughput_tok_s": round(float(stats[1]) / elapsed, 2),
             "slo_attainment": round(float(stats[2]) / max(float(stats[3]), 1.0), 4),
             "kv_bytes_pushed": int(stats[4]),

@@ -35,6 +35,7 @@ def worker_loop(channel, cfg: Dict[str, Any], worker_cls=Worker) -> None:
                             kv_cache_dtype=cfg["cache_config"].cache_dtype, is_driver_worker=True,
                             kv_transport_init=transport_init, **extra)
         reports = cfg.get("reports_output", True)      # tensor-parallel followers compute but do not report
+        pending = None                                  # samples of a deferred step that have not been reported yet
         while True:
             msg = channel.recv()
             cmd, args = msg[0], msg[1:]
@@ -53,6 +54,16 @@ def worker_loop(channel, cfg: Dict[str, Any], worker_cls=Worker) -> None:
                     elif isinstance(result, SamplerOutput):
                         channel.send(("samples", pack_sampler_output(result)))
                         continue
+                elif cmd in ("execute_deferred", "flush"):
+                    # launch the new step first, then report the PREVIOUS one: the device always has
+                    # the next step queued while the engine works on the last one's tokens
+                    new = worker.execute_model(**args[0], defer=True) if cmd == "execute_deferred" else None
+                    prev, pending = pending, new
+                    if prev is None:
+                        channel.send(("ok", None))
+                    else:
+                        channel.send(("samples", pack_sampler_output(prev.resolve())))
+                    continue
                 elif cmd == "bytes_pushed":
                     comm = worker.kvcache_comm_manager.kvcache_comm if worker.kvcache_comm_manager else None
                     result = comm.bytes_pushed if comm else 0

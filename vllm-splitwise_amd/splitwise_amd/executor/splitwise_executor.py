@@ -151,6 +151,23 @@ class SplitwiseExecutor(ExecutorBase):
         decode_out = self._remote_wait() if decode_kwargs is not None else None
         return prompt_out, decode_out
 
+    # pipelined pools: neither call waits for the step it starts
+    supports_pipelined_split = True
+
+    def launch_prompt(self, prompt_kwargs: dict):
+        """Starts a prompt step on the prompt GPU; -> its PendingSamples (done() / resolve())."""
+        return self.driver_worker.execute_model(**prompt_kwargs, defer=True)
+
+    def decode_deferred(self, decode_kwargs: Optional[dict]) -> Optional[SamplerOutput]:
+        """Starts a decode step on the token GPU (None: starts nothing) and returns the samples of
+        the decode step started by the previous call, or None if there was none."""
+        if decode_kwargs is not None:
+            slim = slim_decode_metadata(decode_kwargs["seq_group_metadata_list"])
+            self.channel.send(("execute_deferred", dict(decode_kwargs, seq_group_metadata_list=slim)))
+        else:
+            self.channel.send(("flush",))
+        return self._remote_wait()
+
     def kv_bytes_pushed(self) -> int:
         comm = self.driver_worker.kvcache_comm_manager
         return comm.kvcache_comm.bytes_pushed if comm and comm.kvcache_comm else 0

@@ -78,6 +78,14 @@ class PendingSamples:
         else:
             self._ids, self._lp = next_ids, chosen_lp
 
+    def done(self) -> bool:
+        """True once the step has finished on the device (resolve() will not block)."""
+        return self.event is None or self.event.query()
+
+    def wait(self) -> None:
+        if self.event is not None:
+            self.event.synchronize()
+
     def resolve(self) -> SamplerOutput:
         if self.event is not None:
             self.event.synchronize()
