@@ -48,13 +48,23 @@ def _rank_main(rank: int, port: int, tmpdir: str, result_path: str, blocks: int,
     rng = random.Random(0)
     prompts = {str(i): [rng.randrange(VOCAB) for _ in range(rng.choice([1, 5, 16, 17, 40, 60]))] for i in range(14)}
     lens = {rid: rng.choice([1, 2, 9, 30, 40]) for rid in prompts}
+
+    def generate(prompt, n):
+        seq = list(prompt)
+        for _ in range(n):
+            seq.append(next_token(seq))
+        return seq[len(prompt):]
+
+    # every third request ends on a stop token (its own 4th token, or an earlier equal one)
+    stops = {rid: [generate(prompts[rid], lens[rid])[min(3, lens[rid] - 1)]] for rid in prompts if int(rid) % 3 == 0}
     pending = list(prompts)
     finished = {}
     steps = 0
     while pending or engine.has_unfinished_requests():
         if pending and steps % 2 == 0:                           # requests keep arriving while others decode
             rid = pending.pop(0)
-            engine.add_request(rid, None, SamplingParams(temperature=0.0, max_tokens=lens[rid], ignore_eos=True),
+            engine.add_request(rid, None, SamplingParams(temperature=0.0, max_tokens=lens[rid], ignore_eos=True,
+                                                         stop_token_ids=stops.get(rid, [])),
                                prompt_token_ids=prompts[rid])
         for out in engine.step():
             if out.finished:
@@ -63,14 +73,17 @@ def _rank_main(rank: int, port: int, tmpdir: str, result_path: str, blocks: int,
         assert steps < 2000
     expected = {}
     for rid, prompt in prompts.items():
-        seq = list(prompt)
-        for _ in range(lens[rid]):
-            seq.append(next_token(seq))
-        expected[rid] = seq[len(prompt):]
+        out = generate(prompt, lens[rid])
+        if rid in stops:
+            out = out[:out.index(stops[rid][0]) + 1]
+        expected[rid] = out
     pushed = executor.kv_bytes_pushed()
     preempted = getattr(engine.scheduler, "num_preemptions", 0)
     executor.shutdown()
+    free = engine.scheduler.block_manager.get_num_free_gpu_blocks()
     verdict = "ok" if finished == expected and pushed > 0 else f"mismatch: {finished} != {expected} pushed={pushed}"
+    if verdict == "ok" and free != blocks:
+        verdict = f"{blocks - free} cache blocks were never given back"
     if blocks < 64 and preempted == 0:
         verdict = "the small cache did not force a single preemption: the scenario tests nothing"
     with open(result_path, "w") as f:
@@ -79,7 +92,7 @@ def _rank_main(rank: int, port: int, tmpdir: str, result_path: str, blocks: int,
 
 
 @pytest.mark.parametrize("pipeline", [False, True])  # True: both pools keep a step in flight (placeholder tokens)
-@pytest.mark.parametrize("blocks", [64, 16])       # 16 blocks: decodes run out of cache, sequences are
+@pytest.mark.parametrize("blocks", [64, 12])       # 12 blocks: decodes run out of cache, sequences are
 def test_split_engine_over_gloo_world_size_2(blocks, pipeline):  # preempted, recomputed and handed over again
     with tempfile.TemporaryDirectory() as tmp:
         result = os.path.join(tmp, "result.txt")

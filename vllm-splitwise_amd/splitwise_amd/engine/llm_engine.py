@@ -60,6 +60,7 @@ class LLMEngine:
                                and getattr(self.model_executor, "supports_pipelined_split", False))
         self._prompt_inflight = None    # (pending samples, scheduler outputs, request ids)
         self._decode_inflight = None    # (scheduler outputs, [(group, sequence)])
+        self._free_later: List[Sequence] = []
 
     @classmethod
     def from_engine_args(cls, engine_args: EngineArgs, **kwargs) -> "LLMEngine":
@@ -90,7 +91,7 @@ class LLMEngine:
 
     def has_unfinished_requests(self) -> bool:
         return (self.scheduler.has_unfinished_seqs() or self._inflight is not None
-                or self._prompt_inflight is not None or self._decode_inflight is not None)
+                or self._prompt_inflight is not None or self._decode_inflight is not None or bool(self._free_later))
 
     # --------------------------------------------------------------------- step
     def _check_stop(self, seq: Sequence, params: SamplingParams) -> None:
@@ -167,9 +168,16 @@ class LLMEngine:
         self._inflight = None
         return self._apply_deferred(pending.resolve(), scheduler_outputs, pairs)
 
-    def _apply_deferred(self, output: SamplerOutput, scheduler_outputs: SchedulerOutputs, pairs) -> List[RequestOutput]:
-        """Fills in the tokens of a step whose sequences have carried placeholders since its launch."""
+    def _apply_deferred(self, output: SamplerOutput, scheduler_outputs: SchedulerOutputs, pairs,
+                        still_running=()) -> List[RequestOutput]:
+        """Fills in the tokens of a step whose sequences have carried placeholders since its launch.
+        ``still_running``: ids of the sequences in a newer step that is already in flight (split
+        pools only): their blocks must outlive that step, because the prompt GPU does not queue
+        behind the token GPU's stream when it writes new KV into reused blocks."""
         now = time.time()
+        for seq in self._free_later:                     # their speculative extra step has resolved by now
+            self.scheduler.free_seq(seq)
+        self._free_later = []
         reported: List[SequenceGroup] = []
         for (group, seq), out in zip(pairs, output):
             if not seq.has_placeholder():
@@ -184,10 +192,14 @@ class LLMEngine:
                 # ended by length when the step was launched; a stop token takes precedence as in _check_stop
                 if sample.output_token in group.sampling_params.stop_token_ids:
                     seq.status = SequenceStatus.FINISHED_STOPPED
+                self.scheduler.free_seq(seq)            # no-op when the blocks went back at launch
             else:
                 self._check_stop(seq, group.sampling_params)
                 if seq.is_finished():
-                    self.scheduler.free_seq(seq)
+                    if seq.seq_id in still_running:
+                        self._free_later.append(seq)
+                    else:
+                        self.scheduler.free_seq(seq)
                     if group in self.scheduler.waiting:      # preempted for recomputation in the meantime
                         self.scheduler.waiting.remove(group)
             group.maybe_set_first_token_time(now)
@@ -205,9 +217,12 @@ class LLMEngine:
                 continue            # a stop token of the previous step ended it; this step's sample is dropped
             seq.append_placeholder()
             if self._finished_by_length(seq, group.sampling_params):
-                # device work is stream-ordered, so the blocks can be handed out again at once
                 seq.status = SequenceStatus.FINISHED_LENGTH_CAPPED
-                self.scheduler.free_seq(seq)
+                # co-located: device work is stream-ordered, so the blocks can be handed out again at
+                # once.  Split pools: the prompt GPU writes new KV into the token GPU's blocks on its own
+                # clock, so these blocks stay taken until the step that still reads them has resolved.
+                if not self.pipeline_split:
+                    self.scheduler.free_seq(seq)
         self.scheduler.free_finished_seq_groups()
 
     def _step_split_pipelined(self) -> List[RequestOutput]:
@@ -255,7 +270,8 @@ class LLMEngine:
             if self._decode_inflight is not None:
                 outs_prev, pairs_prev = self._decode_inflight
                 self._decode_inflight = None
-                outputs += self._apply_deferred(previous, outs_prev, pairs_prev)
+                newer = {seq.seq_id for _, seq in pairs} if pairs is not None else ()
+                outputs += self._apply_deferred(previous, outs_prev, pairs_prev, still_running=newer)
             if pairs is not None:
                 self._launch_bookkeeping(pairs)
                 self._decode_inflight = (outs_d, pairs)
