@@ -2,6 +2,9 @@
 """Tunes the ROCm BLAS solution of the decode-step GEMMs (torch TunableOp) and reports the gain.
 
   python tools/tune_gemm.py <model preset> <out.csv> [M ...]
+
+Measured on the bench's shapes (profiles/r1/gemm_tunableop_v1.log): 1-2 % at 200-256 rows, 3-8 % on the
+prompt steps' shapes -- too little to carry a tuned-solution file around, so bench.py does not load one.
 """
 import os
 import sys
@@ -40,7 +43,8 @@ def main():
     h, ffn = cfg["hidden_size"], cfg["intermediate_size"]
     heads, kvh = cfg["num_attention_heads"], cfg["num_key_value_heads"]
     d = h // heads
-    shapes = {"qkv": ((heads + 2 * kvh) * d, h), "o": (h, h), "gate_up": (2 * ffn, h), "down": (h, ffn)}
+    shapes = {"qkv": ((heads + 2 * kvh) * d, h), "o": (h, h), "gate_up": (2 * ffn, h), "down": (h, ffn),
+              "lm_head": (cfg["vocab_size"], h)}
     dtype = torch.bfloat16 if cfg["torch_dtype"] == "bfloat16" else torch.float16
     tun = torch.cuda.tunable
     for name, (n, k) in shapes.items():
@@ -54,7 +58,7 @@ def main():
             gb = (n * k + m * k + m * n) * 2 / 1e9
             print(f"{name:8s} M={m:4d} N={n:6d} K={k:6d}: default {base:7.1f} us ({gb / base * 1e6:6.0f} GB/s)  "
                   f"tuned {tuned:7.1f} us ({gb / tuned * 1e6:6.0f} GB/s)  x{base / tuned:4.2f}", flush=True)
-    tun.write_file(out)
+    # the results file (<out> with the device ordinal before the extension) is written when the process exits
 
 
 if __name__ == "__main__":
