@@ -81,7 +81,7 @@ struct PfContext {
 };
 
 template <typename act_t, int HEAD, bool CTX>
-__global__ void __launch_bounds__(kPfWaves * 64, HEAD <= 128 && !CTX ? 2 : 1)
+__global__ void __launch_bounds__(kPfWaves * 64, HEAD <= 128 ? 2 : 1)
 prefill_attention_kernel(uint16_t* __restrict__ out, const uint16_t* __restrict__ q,
                          const uint16_t* __restrict__ k, const uint16_t* __restrict__ v,
                          const int32_t* __restrict__ seq_starts, const int32_t* __restrict__ seq_lens,
