@@ -3,5 +3,5 @@
 #include "paged_attention.cuh"
 
 namespace sw {
-int pa_dispatch_bf16(const PaArgs& a) { return dispatch_pa<bf16_t, false, 4>(a); }
+int pa_dispatch_bf16(const PaArgs& a) { return dispatch_pa<bf16_t, false, 8>(a); }
 }  // namespace sw

@@ -86,7 +86,11 @@ template <> struct Dot2<f16_t> {
 template <> struct Dot2<bf16_t> {
   static constexpr bool kAvailable = true;
   __device__ static __forceinline__ float run(uint32_t a, uint32_t b, float c) {
-    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(b16x2, a), __builtin_bit_cast(b16x2, b), c, false);
+    // The instruction itself, not __builtin_amdgcn_fdot2_f32_bf16: with the builtin the scheduler
+    // hoists so many loads ahead of the dot products that the 4- and 8-head kernels need more
+    // than 300 registers (one wave per SIMD, spills), where the f16 twin needs 130-160.
+    asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(c) : "v"(a), "v"(b));
+    return c;
   }
 };
 

@@ -38,11 +38,11 @@ class PagedAttentionImpl:
     def query_group_width(num_heads: int, num_kv_heads: int, head_size: int, block_size: int,
                           dtype: torch.dtype, kv_cache_dtype: str) -> int:
         """Query heads one workgroup of the decode kernel serves from a single pass over K and V
-        (the dispatch rule of csrc/paged_attention.cuh: powers of two up to 8 for f16, 4 for bf16,
+        (the dispatch rule of csrc/paged_attention.cuh: powers of two up to 8 for f16 and bf16,
         2 for bf16 over an fp8 cache, 1 for fp32; head sizes 64 / 128 and blocks of 16 / 32 only)."""
         if head_size not in (64, 128) or block_size < 16:
             return 1
-        cap = {torch.float16: 8, torch.bfloat16: 2 if kv_cache_dtype == "fp8_e5m2" else 4}.get(dtype, 1)
+        cap = {torch.float16: 8, torch.bfloat16: 2 if kv_cache_dtype == "fp8_e5m2" else 8}.get(dtype, 1)
         group = num_heads // num_kv_heads
         width = 8 if group % 8 == 0 else 4 if group % 4 == 0 else 2 if group % 2 == 0 else 1
         return min(width, cap)
