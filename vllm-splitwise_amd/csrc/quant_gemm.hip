@@ -220,7 +220,7 @@ template <int CP, int ROWS, typename ValOf, typename RowOf>
 __device__ __forceinline__ void combine_and_store(ValOf val_of, RowOf row_of, bool col_ok, int ncol,
                                                   uint16_t* __restrict__ c, int M, int N, int ksplit,
                                                   float* __restrict__ partials, int32_t* __restrict__ counters,
-                                                  int tile, int* s_last) {
+                                                  int tile, int split, int* s_last) {
   const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(partials, 0, (int)((size_t)ksplit * M * N * 4), 0x00020000);
   bool last = true;
   if (ksplit > 1) {
@@ -228,7 +228,7 @@ __device__ __forceinline__ void combine_and_store(ValOf val_of, RowOf row_of, bo
     for (int i = 0; i < ROWS; ++i) {
       const int m = row_of(i);
       if (m >= M || !col_ok) continue;
-      const int off = (int)((((size_t)blockIdx.z * M + m) * N + ncol) * 4);
+      const int off = (int)((((size_t)split * M + m) * N + ncol) * 4);
       if constexpr (CP == 4) {
         const u32x4 v = {__float_as_uint(val_of(i, 0)), __float_as_uint(val_of(i, 1)), __float_as_uint(val_of(i, 2)),
                          __float_as_uint(val_of(i, 3))};
@@ -343,7 +343,7 @@ gptq_gemm_kwaves_kernel(uint16_t* __restrict__ c, const uint16_t* __restrict__ a
   };
   auto val_of = [&](int i, int cc) { return vals[i][cc]; };
   combine_and_store<CP, 2 * MT>(val_of, row_of, col_ok, ncol, c, M, N, ksplit, partials, counters, blockIdx.x,
-                                &s_last);
+                                blockIdx.z, &s_last);
 }
 
 // Variant "tiled" (more than 32 rows of A): grid (groups of 8 column tiles, row tiles of 32*MT,
@@ -358,7 +358,8 @@ template <int MT, int CP>
 __global__ void __launch_bounds__(kGemmWaves * 64)
 gptq_gemm_tiled_kernel(uint16_t* __restrict__ c, const uint16_t* __restrict__ a, const uint32_t* __restrict__ qweight,
                        const uint32_t* __restrict__ qzeros, const uint16_t* __restrict__ scales, int M, int N, int K,
-                       int group_size, int ksplit, float* __restrict__ partials, int32_t* __restrict__ counters) {
+                       int group_size, int ksplit, int col_tiles, int row_tiles, float* __restrict__ partials,
+                       int32_t* __restrict__ counters) {
   using wvec = typename WordVec<CP>::type;
   using svec = typename WordVec<CP>::scale_t;
   constexpr int PF = 8;                               // weight steps in flight
@@ -374,12 +375,22 @@ gptq_gemm_tiled_kernel(uint16_t* __restrict__ c, const uint16_t* __restrict__ a,
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 31, half = lane >> 5;
-  const int ncol = (blockIdx.x * kGemmWaves + wave) * 32 * CP + CP * j;
+  // Workgroup ids go round-robin over the 8 XCDs (each with its own L2).  The row tiles of one
+  // column group stream the same weights, so they are made neighbours ON ONE XCD: id -> (xcd =
+  // id % 8, slot = id / 8), and the slots of an XCD walk (row tile fastest, column group, k split).
+  const int total = col_tiles * row_tiles * ksplit;
+  const int per_xcd = (total + 7) / 8;
+  const int work = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+  if (work >= total) return;                          // workgroup-uniform (the grid is padded to 8 * per_xcd)
+  const int row_tile = work % row_tiles;
+  const int col_tile = (work / row_tiles) % col_tiles;
+  const int split = work / (row_tiles * col_tiles);
+  const int ncol = (col_tile * kGemmWaves + wave) * 32 * CP + CP * j;
   const bool col_ok = ncol < N;
   const int ncl = col_ok ? ncol : 0;
-  const int m0 = blockIdx.y * BM;
+  const int m0 = row_tile * BM;
   const int chunks = K / kChunkK;
-  const int c_begin = (int)((int64_t)chunks * blockIdx.z / ksplit), c_end = (int)((int64_t)chunks * (blockIdx.z + 1) / ksplit);
+  const int c_begin = (int)((int64_t)chunks * split / ksplit), c_end = (int)((int64_t)chunks * (split + 1) / ksplit);
   const int s_begin = SPC * c_begin, s_end = SPC * c_end;
   const int spg = group_size / 16;
 
@@ -487,7 +498,7 @@ gptq_gemm_tiled_kernel(uint16_t* __restrict__ c, const uint16_t* __restrict__ a,
   };
   auto val_of = [&](int i, int cc) { return acc[i / 16][cc][i % 16]; };
   combine_and_store<CP, 16 * MT>(val_of, row_of, col_ok, ncol, c, M, N, ksplit, partials, counters,
-                                 blockIdx.y * gridDim.x + blockIdx.x, &s_last);
+                                 row_tile * col_tiles + col_tile, split, &s_last);
 }
 
 // ------------------------------------------------------------------ GPTQ, plain (unshuffled) weights + g_idx
@@ -947,7 +958,7 @@ int sw_gptq_gemm(void* c, const void* a, const uint32_t* qweight, const uint32_t
     const int tile_cols = 32 * cp * kGemmWaves;
     const int col_tiles = (N + tile_cols - 1) / tile_cols;
     const int ks = pick_ksplit(col_tiles * row_tiles, K / kChunkK, 2, M, N, avail, 1, 256);
-    const dim3 grid(col_tiles, row_tiles, ks);
+    const dim3 grid((col_tiles * row_tiles * ks + 7) / 8 * 8);
     const size_t lds = (size_t)2 * 32 * mt * kARow;
 #define SW_GPTQ_TILED(MT_, CP_)                                                                                 \
   do {                                                                                                          \
@@ -956,7 +967,7 @@ int sw_gptq_gemm(void* c, const void* a, const uint32_t* qweight, const uint32_t
       SW_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                     \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                  \
     hipLaunchKernelGGL(kern, grid, dim3(kGemmWaves * 64), lds, st, out, ap, qweight, qzeros, sp, M, N, K,       \
-                       group_size, ks, partials, counters);                                                     \
+                       group_size, ks, col_tiles, row_tiles, partials, counters);                               \
   } while (0)
     if (mt == 1 && cp == 2) SW_GPTQ_TILED(1, 2);
     else if (mt == 1) SW_GPTQ_TILED(1, 4);
