@@ -121,6 +121,8 @@ def test_http_generate_and_openai_routes():
         assert [len(c["token_ids"][0]) for c in chunks] == [1, 2, 3]
     engine = AsyncLLMEngine(engine=_engine())
     with TestClient(openai_server.build_app(engine, "llama-tiny")) as client:
+        metrics = client.get("/metrics/")
+        assert metrics.status_code == 200 and "vllm:num_requests_running" in metrics.text
         assert client.get("/v1/models").json()["data"][0]["id"] == "llama-tiny"
         r = client.post("/v1/completions", json={"model": "llama-tiny", "prompt": [prompt, prompt[:3]], "max_tokens": 4,
                                                  "temperature": 0.0, "ignore_eos": True})

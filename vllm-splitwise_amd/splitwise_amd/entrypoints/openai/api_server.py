@@ -1,4 +1,4 @@
-"""OpenAI-style routes (vllm/entrypoints/openai/api_server.py:161-196): ``/health``,
+"""OpenAI-style routes (vllm/entrypoints/openai/api_server.py:150-196): ``/metrics``, ``/health``,
 ``/v1/models``, ``/v1/completions`` (plain and server-sent-event streaming) and
 ``/v1/chat/completions``.  Prompts may be strings (with a tokenizer on the engine), one list of
 token ids, or a list of such lists, as the OpenAI completions API allows.  Chat needs a
@@ -42,6 +42,13 @@ def _sampling_params(body: dict) -> SamplingParams:
 
 def build_app(engine: AsyncLLMEngine, served_model: str) -> FastAPI:
     app = FastAPI()
+    try:                                            # /metrics (openai/api_server.py:150-152)
+        from prometheus_client import make_asgi_app
+        from ...engine.metrics import _metrics
+        _metrics()                                  # registers the vllm:* series even before the first step
+        app.mount("/metrics", make_asgi_app())
+    except ImportError:                             # pragma: no cover - the front works without it
+        pass
 
     @app.get("/health")
     async def health() -> Response:
