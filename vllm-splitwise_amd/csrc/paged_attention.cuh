@@ -82,6 +82,7 @@ template <> struct Dot2<f16_t> {
   __device__ static __forceinline__ float run(uint32_t a, uint32_t b, float c) {
     return __builtin_amdgcn_fdot2(__builtin_bit_cast(h16x2, a), __builtin_bit_cast(h16x2, b), c, false);
   }
+  __device__ static __forceinline__ void settle(float&) {}
 };
 template <> struct Dot2<bf16_t> {
   static constexpr bool kAvailable = true;
@@ -92,6 +93,11 @@ template <> struct Dot2<bf16_t> {
     asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(c) : "v"(a), "v"(b));
     return c;
   }
+  // A dot result may be read by a different VALU or memory instruction only 3 wait states after
+  // the dot issued, and overwritten only after 4; the hardware does not interlock this and the
+  // compiler, which inserts the s_nop for its own dot instructions, cannot see into the asm above.
+  // Call this on the last result of a chain before anything but another dot2c touches it.
+  __device__ static __forceinline__ void settle(float& c) { asm volatile("s_nop 3" : "+v"(c)); }
 };
 
 // N cache elements (N/2 pairs) -> dwords of activation-dtype pairs.  fp8 e5m2 is the high byte of
@@ -263,6 +269,7 @@ paged_attention_kernel(void* __restrict__ out_,            // v1: [S,H,HEAD]; v2
     // ------------------------------------------------------ online softmax
 #pragma unroll
     for (int h = 0; h < QG; ++h) {
+      if constexpr (PACKED) Dot2<act_t>::settle(qk[h]);
       float s = qk[h] * scale;
       s += (slope[h] != 0.f) ? slope[h] * (float)(token - ctx + 1) : 0.f;
       const float gmax = wave_max(valid ? s : -FLT_MAX);
@@ -375,6 +382,13 @@ paged_attention_kernel(void* __restrict__ out_,            // v1: [S,H,HEAD]; v2
   }
 
   // ------------------------------------------------ merge the four waves
+  // (inside the loop the next reader of acc, the rescale by alpha, sits behind the whole Q.K phase)
+  if constexpr (PACKED) {
+#pragma unroll
+    for (int h = 0; h < QG; ++h)
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) Dot2<act_t>::settle(acc[h][it]);
+  }
   float* acc_s = red_s;                                     // [4][QG][HEAD]
   float* m_s = red_s + kPaWaves * QG * HEAD;                // [4][QG]
   float* l_s = m_s + kPaWaves * QG;                         // [4][QG]
