@@ -131,13 +131,17 @@ class Scheduler:
         """Optional prefill batching (off by default; the reference admits a prompt the moment it
         fits): while sequences are decoding, waiting prompts are held until at least
         ``prefill_batch_tokens`` tokens of them have gathered or the oldest has waited
-        ``prefill_max_wait`` seconds, so that a prompt step runs GEMMs of several prompts' rows."""
+        ``prefill_max_wait`` seconds, so that a prompt step runs GEMMs of several prompts' rows.
+        The wait shrinks with the load: a prompt step stalls every running sequence for its whole
+        length, so batching pays in proportion to how many are running (full wait from 64 up);
+        with few running it would only add to the time to the first token."""
         cfg = self.scheduler_config
         want = getattr(cfg, "prefill_batch_tokens", 0)
         if want <= 0 or not self.waiting or not self.running:
             return False
         waited = time.monotonic() - self.waiting[0].metrics.arrival_time
-        if waited < 0 or waited >= cfg.prefill_max_wait:
+        running = sum(group.num_seqs(status=SequenceStatus.RUNNING) for group in self.running)
+        if waited < 0 or waited >= cfg.prefill_max_wait * min(1.0, running / 64.0):
             return False
         have = 0
         for group in self.waiting:
