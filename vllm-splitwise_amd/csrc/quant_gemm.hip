@@ -670,82 +670,115 @@ __global__ void awq_dequantize_kernel(uint16_t* __restrict__ out, const uint32_t
   *reinterpret_cast<uint4*>(out + (size_t)k * N + 8 * wc) = awq_dequant8(qweight[idx], cols);
 }
 
-// grid (column tiles of 256, row tiles of 32, k splits); 4 waves each owning a run of 16-k steps.
-// LDS per wave: 16 rows x (512 + 16) bytes image; the reduction buffer reuses the same memory.
-constexpr int kAwqRow = 512 + 16;                   // bytes per image row (pad: rows land on different banks)
-constexpr int kAwqImage = 16 * kAwqRow;
+// Fused GEMM, up to 32 rows of A per workgroup.  Grid (column tiles of 256 x row tiles, 1, k splits);
+// the 8 waves of a workgroup split its k range into runs of 16-k steps and add up in LDS.
+//
+// A lane (j = lane & 31, half = lane >> 5) loads the 8 words of ONE word column for k rows
+// 8*half .. 8*half+7 of a step: an 8 k x 8 column block of nibbles.  The matrix core wants, per
+// column, 8 consecutive k in one lane -- a transpose that stays inside the lane: v_perm puts byte
+// b of two consecutive rows into the low bytes of the two halves of a dword, where the two masks
+// of the magic-number unpacking find the (k, k+1) pair of the byte's low-nibble column and the
+// pair of its high-nibble column.  Accumulator c therefore holds columns n0 + 8 j + c, and a
+// thread ends up with runs of adjacent columns to store.
+constexpr int kAwqWaves = 8;
 
-__global__ void __launch_bounds__(256, 2)
+struct AwqLane {
+  h2 zt[8];    // per logical column: -(1024 + zero) (low nibble of its byte) or -(64 + zero) (high nibble)
+  h2 s[8];     // per logical column: scale in both halves
+};
+
+// logical column of nibble p of a word (dequantize.cuh:40-56 packs 0 2 4 6 1 3 5 7)
+__host__ __device__ constexpr int awq_col_of_nibble(int p) { return 2 * (p & 3) + (p >> 2); }
+
+__device__ __forceinline__ AwqLane awq_lane_cols(uint32_t zw, uint4 sc) {
+  AwqLane c;
+  const uint32_t sw[4] = {sc.x, sc.y, sc.z, sc.w};
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    const int col = awq_col_of_nibble(p);
+    const uint32_t z = (zw >> (4 * p)) & 0xfu;
+    if (p & 1) {
+      c.zt[col] = splat((_Float16)(-64 - (int)z));
+    } else {
+      const uint32_t zb = 0xe400u | z;                // -(1024 + z)
+      c.zt[col] = as_h2(zb | (zb << 16));
+    }
+    const uint32_t sb = (sw[col >> 1] >> (16 * (col & 1))) & 0xffffu;
+    c.s[col] = as_h2(sb | (sb << 16));
+  }
+  return c;
+}
+
+__global__ void __launch_bounds__(kAwqWaves * 64)
 awq_gemm_kernel(uint16_t* __restrict__ c, const uint16_t* __restrict__ a, const uint32_t* __restrict__ qweight,
                 const uint16_t* __restrict__ scales, const uint32_t* __restrict__ qzeros, int M, int N, int K,
-                int group_size, int ksplit, float* __restrict__ partials, int32_t* __restrict__ counters) {
+                int group_size, int ksplit, int row_tiles, float* __restrict__ partials,
+                int32_t* __restrict__ counters) {
   extern __shared__ __attribute__((aligned(16))) float red[];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __shared__ int s_last;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int j = lane & 31, half = lane >> 5;
-  char* image = reinterpret_cast<char*>(red) + wave * kAwqImage;
   const int nw = N / 8;
-  const int n0 = blockIdx.x * 256;
-  const int wcol = n0 / 8 + j;                        // this lane's word column when loading
+  // row tiles of one column tile are neighbours in launch order: they stream the same weights
+  const int col_tile = blockIdx.x / row_tiles, row_tile = blockIdx.x % row_tiles;
+  const int n0 = col_tile * 256;
+  const int wcol = n0 / 8 + j;                        // this lane's word column
   const bool w_ok = wcol < nw;
   const int wcl = w_ok ? wcol : 0;
-  const int m0 = blockIdx.y * 32;
+  const int m0 = row_tile * 32;
 
   const int steps = K / 16;
-  const int nwv = ksplit * 4, wg = blockIdx.z * 4 + wave;
+  const int nwv = ksplit * kAwqWaves, wg = blockIdx.z * kAwqWaves + wave;
   const int s_begin = (int)((int64_t)steps * wg / nwv), s_end = (int)((int64_t)steps * (wg + 1) / nwv);
 
-  f32x16 acc[1][8];
+  f32x16 acc[8];
 #pragma unroll
   for (int cb = 0; cb < 8; ++cb)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[0][cb][r] = 0.f;
+    for (int r = 0; r < 16; ++r) acc[cb][r] = 0.f;
 
   const uint16_t* ap = a + (size_t)min(m0 + j, M - 1) * K + 8 * half;
-  // transposing read: lane 4q+p of a 16-lane group supplies row q, columns 4p..4p+3 of a
-  // 4 x 16 block and receives rows 0..3 of column (lane & 15); groups 0,1 serve k 0..7 and
-  // groups 2,3 serve k 8..15 of columns 0..15 / 16..31 of a 32-column block.
-  const int tr_q = (lane & 15) >> 2, tr_p = lane & 3, tr_g = lane >> 4;
-  const int tr_off = (8 * (tr_g >> 1) + tr_q) * kAwqRow + (16 * (tr_g & 1) + 4 * tr_p) * 2;
+  const uint32_t* wp = qweight + (size_t)(8 * half) * nw + wcl;
 
-  AwqCols cols;
+  AwqLane cols;
   int cur_group = -1;
-  constexpr int PF = 4;                               // 16-k steps of weight words in flight per wave
+  constexpr int PF = 4;                               // 16-k steps in flight per wave
   uint32_t wq[PF][8];
   f16x8 af[PF];
   auto load_step = [&](auto SLOT, int s) {
     constexpr int slot = decltype(SLOT)::value;
     if (s >= s_end) return;
 #pragma unroll
-    for (int t = 0; t < 8; ++t) wq[slot][t] = qweight[(size_t)(16 * s + 2 * t + half) * nw + wcl];
+    for (int i = 0; i < 8; ++i) wq[slot][i] = wp[(size_t)(16 * s + i) * nw];
     af[slot] = *reinterpret_cast<const f16x8*>(ap + 16 * s);
   };
   auto run_step = [&](auto SLOT, int s) {
     constexpr int slot = decltype(SLOT)::value;
     const int g = 16 * s / group_size;
     if (g != cur_group) {                             // wave-uniform; group data is L2-resident
-      cols = awq_cols(qzeros[(size_t)g * nw + wcl], *reinterpret_cast<const uint4*>(scales + (size_t)g * N + 8 * wcl));
+      cols = awq_lane_cols(qzeros[(size_t)g * nw + wcl], *reinterpret_cast<const uint4*>(scales + (size_t)g * N + 8 * wcl));
       cur_group = g;
     }
+    const h2 y16 = splat((_Float16)0.0625f);
+    union { uint32_t u[4]; f16x8 f; } b[8];
 #pragma unroll
-    for (int t = 0; t < 8; ++t) {
-      uint4 d = awq_dequant8(wq[slot][t], cols);
-      if (!w_ok) d = make_uint4(0, 0, 0, 0);
-      *reinterpret_cast<uint4*>(image + (2 * t + half) * kAwqRow + 16 * j) = d;
+    for (int m = 0; m < 4; ++m) {                     // k rows 2m, 2m+1 of the lane's eight
+      const uint32_t w0 = wq[slot][2 * m], w1 = wq[slot][2 * m + 1];
+#pragma unroll
+      for (int byte = 0; byte < 4; ++byte) {
+        const uint32_t u = __builtin_amdgcn_perm(w1, w0, 0x0c000c00u | (uint32_t)byte | ((uint32_t)(4 + byte) << 16));
+        const int c_lo = awq_col_of_nibble(2 * byte), c_hi = awq_col_of_nibble(2 * byte + 1);
+        const h2 q_lo = as_h2((u & 0x000f000fu) | kMagic);
+        const h2 q_hi = as_h2((u & 0x00f000f0u) | kMagic);
+        b[c_lo].u[m] = as_u32((q_lo + cols.zt[c_lo]) * cols.s[c_lo]);
+        b[c_hi].u[m] = as_u32((q_hi * y16 + cols.zt[c_hi]) * cols.s[c_hi]);
+      }
     }
     const f16x8 a_frag = af[slot];
     load_step(SLOT, s + PF);                          // the slot's registers are free again
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 #pragma unroll
-    for (int cb = 0; cb < 8; ++cb) {
-      const char* base = image + tr_off + cb * 64;
-      const i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_i16x4_ptr)(base));
-      const i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_i16x4_ptr)(base + 4 * kAwqRow));
-      union { struct { i16x4 a, b; } p; f16x8 f; } bf;
-      bf.p.a = lo;
-      bf.p.b = hi;
-      acc[0][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_frag, bf.f, acc[0][cb], 0, 0, 0);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");    // the image is rewritten next step
+    for (int cb = 0; cb < 8; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_frag, b[cb].f, acc[cb], 0, 0, 0);
   };
   static_for<PF>([&](auto SLOT) { load_step(SLOT, s_begin + decltype(SLOT)::value); });
   for (int s = s_begin; s < s_end; s += PF) {
@@ -754,87 +787,33 @@ awq_gemm_kernel(uint16_t* __restrict__ c, const uint16_t* __restrict__ a, const 
       if (s + i < s_end) run_step(SLOT, s + i);
     });
   }
-  // accumulator cb holds column n0 + 32*cb + j; the four waves' sums meet in LDS (which reuses
-  // the image memory) in four passes of 4 accumulator rows each.
-  __syncthreads();
-  float* buf = red;
-  const int tile = blockIdx.y * gridDim.x + blockIdx.x;
-  __shared__ int s_last;
-  float sum[4][8];                                    // [pass][cb]: row r = 4*pass + wave
+
+  // The eight waves' sums meet in LDS in four passes of 4 accumulator rows.  After pass p wave w
+  // owns accumulator row 4p + (w & 3) = matrix row m0 + 8p + 4*half + (w & 3), and of the lane's
+  // 8 columns the four starting at 4*(w >> 2).
+  const int cq = wave >> 2, rw = wave & 3;
+  float vals[4][4];
 #pragma unroll
   for (int pass = 0; pass < 4; ++pass) {
     __syncthreads();
 #pragma unroll
     for (int cb = 0; cb < 8; ++cb)
 #pragma unroll
-      for (int r4 = 0; r4 < 4; ++r4) buf[((wave * 8 + cb) * 4 + r4) * 64 + lane] = acc[0][cb][4 * pass + r4];
+      for (int r4 = 0; r4 < 4; ++r4) red[((wave * 8 + cb) * 4 + r4) * 64 + lane] = acc[cb][4 * pass + r4];
     __syncthreads();
 #pragma unroll
-    for (int cb = 0; cb < 8; ++cb) {
+    for (int cc = 0; cc < 4; ++cc) {
       float v = 0.f;
 #pragma unroll
-      for (int w = 0; w < 4; ++w) v += buf[((w * 8 + cb) * 4 + wave) * 64 + lane];
-      sum[pass][cb] = v;
+      for (int w = 0; w < kAwqWaves; ++w) v += red[((w * 8 + 4 * cq + cc) * 4 + rw) * 64 + lane];
+      vals[pass][cc] = v;
     }
   }
-  // this thread owns row m0 + 8*pass + 4*half + wave, columns n0 + 32*cb + j
-  bool last = true;
-  const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(partials, 0, (int)((size_t)ksplit * M * N * 4), 0x00020000);
-  if (ksplit > 1) {
-#pragma unroll
-    for (int pass = 0; pass < 4; ++pass) {
-      const int m = m0 + 8 * pass + 4 * half + wave;
-      if (m >= M) continue;
-#pragma unroll
-      for (int cb = 0; cb < 8; ++cb) {
-        const int n = n0 + 32 * cb + j;
-        if (n < N)
-          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(sum[pass][cb]), rsrc,
-                                                (int)((((size_t)blockIdx.z * M + m) * N + n) * 4), 0, kAuxSystem);
-      }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) s_last = (arrive(&counters[tile]) == ksplit - 1);
-    __syncthreads();
-    last = s_last != 0;
-  }
-  if (!last) return;
-  if (ksplit > 1) {
-#pragma unroll
-    for (int pass = 0; pass < 4; ++pass)
-#pragma unroll
-      for (int cb = 0; cb < 8; ++cb) sum[pass][cb] = 0.f;
-    for (int z = 0; z < ksplit; ++z) {                  // fixed order; one batch of loads per split
-      float p[4][8];
-#pragma unroll
-      for (int pass = 0; pass < 4; ++pass) {
-        const int m = m0 + 8 * pass + 4 * half + wave;
-#pragma unroll
-        for (int cb = 0; cb < 8; ++cb) {
-          const int n = n0 + 32 * cb + j;
-          const int off = (m < M && n < N) ? (int)((((size_t)z * M + m) * N + n) * 4) : 0;
-          p[pass][cb] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, off, 0, kAuxSystem));
-        }
-      }
-#pragma unroll
-      for (int pass = 0; pass < 4; ++pass)
-#pragma unroll
-        for (int cb = 0; cb < 8; ++cb) sum[pass][cb] += p[pass][cb];
-    }
-  }
-#pragma unroll
-  for (int pass = 0; pass < 4; ++pass) {
-    const int m = m0 + 8 * pass + 4 * half + wave;
-    if (m >= M) continue;
-#pragma unroll
-    for (int cb = 0; cb < 8; ++cb) {
-      const int n = n0 + 32 * cb + j;
-      if (n < N) c[(size_t)m * N + n] = float_to_f16_bits(sum[pass][cb]);
-    }
-  }
-  if (ksplit > 1 && threadIdx.x == 0)
-    __hip_atomic_store(&counters[tile], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const int ncol = n0 + 8 * j + 4 * cq;
+  auto row_of = [&](int pass) { return m0 + 8 * pass + 4 * half + rw; };
+  auto val_of = [&](int pass, int cc) { return vals[pass][cc]; };
+  combine_and_store<4, 4>(val_of, row_of, w_ok, ncol, c, M, N, ksplit, partials, counters, blockIdx.x, blockIdx.z,
+                          &s_last);
 }
 
 // how many ways to split k across workgroups: aim at two workgroups per compute unit, keep at
@@ -1023,12 +1002,15 @@ int sw_awq_gemm(void* c, const void* a, const uint32_t* qweight, const void* sca
   int32_t* counters = static_cast<int32_t*>(workspace);
   float* partials = reinterpret_cast<float*>(static_cast<char*>(workspace) + kCounterBytes);
   const int col_tiles = (N + 255) / 256, row_tiles = (M + 31) / 32;
-  const int ks = pick_ksplit(col_tiles * row_tiles, K / 16, 8, M, N, workspace_bytes, 4, 512);
-  const size_t lds = (size_t)4 * kAwqImage;           // four wave images; the reduction buffer reuses them
-  static_assert(4 * 8 * 4 * 64 * 4 <= 4 * kAwqImage, "the reduction buffer must fit in the LDS images");
-  hipLaunchKernelGGL(awq_gemm_kernel, dim3(col_tiles, row_tiles, ks), dim3(256), lds, static_cast<hipStream_t>(stream),
-                     static_cast<uint16_t*>(c), static_cast<const uint16_t*>(a), qweight,
-                     static_cast<const uint16_t*>(scales), qzeros, M, N, K, group_size, ks, partials, counters);
+  // one workgroup per compute unit (64 KB of LDS, 238 registers) and a single round of them:
+  // a second, partly filled round costs more than the idle units of a first one that is not full
+  const int tiles = col_tiles * row_tiles;
+  const int ks = pick_ksplit(tiles, K / 16, 4, M, N, workspace_bytes, kAwqWaves, tiles * (256 / tiles > 1 ? 256 / tiles : 1));
+  const size_t lds = (size_t)kAwqWaves * 8 * 4 * 64 * 4;        // one pass of the cross-wave reduction
+  hipLaunchKernelGGL(awq_gemm_kernel, dim3(col_tiles * row_tiles, 1, ks), dim3(kAwqWaves * 64), lds,
+                     static_cast<hipStream_t>(stream), static_cast<uint16_t*>(c), static_cast<const uint16_t*>(a),
+                     qweight, static_cast<const uint16_t*>(scales), qzeros, M, N, K, group_size, ks, row_tiles,
+                     partials, counters);
   SW_CHECK_LAUNCH();
   return SW_OK;
 }
