@@ -59,6 +59,10 @@ def parse_args():
     ap.add_argument("--prefill-max-wait", type=float, default=0.08, help="... or the oldest has waited this long (s)")
     ap.add_argument("--no-pipeline-steps", action="store_true",
                     help="wait for a step's tokens before scheduling the next step (the reference's loop)")
+    ap.add_argument("--quantization", default=None, choices=[None, "gptq", "awq"],
+                    help="int4 weights (fp16 activations); the default workload is unquantised bf16")
+    ap.add_argument("--kv-cache-dtype", default="auto", choices=["auto", "fp8_e5m2"])
+    ap.add_argument("--dtype", default=None, help="activation dtype (default bf16, fp16 with --quantization)")
     ap.add_argument("--enforce-eager", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -195,7 +199,10 @@ def measure_attention_roofline(engine, samples):
            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
            "avg_launch_us": round(avg_s * 1e6, 2), "launches_timed": launches,
            "alg_bytes_per_launch": int(alg_bytes / launches)}
-    out.update(pmc_traffic())
+    pmc = pmc_traffic()
+    # the counter summary belongs to the workload it was collected on
+    if pmc and abs(pmc["traffic_alg_bytes_per_launch"] - out["alg_bytes_per_launch"]) <= 0.05 * out["alg_bytes_per_launch"]:
+        out.update(pmc)
     return out
 
 
@@ -240,8 +247,13 @@ def main():
     conc = args.concurrency
     warmup = args.warmup if args.warmup is not None else 3 * conc
     seq_blocks = -(-(args.prompt_len + args.decode_len + 1) // 16)
+    dtype = args.dtype or ("float16" if args.quantization else "bfloat16")
+    dtype_tag = {"bfloat16": "bf16", "float16": "f16", "half": "f16", "float32": "f32"}.get(dtype, dtype)
+    variant = dtype_tag + (f" {args.quantization} int4" if args.quantization else "") + \
+        (" fp8 KV cache" if args.kv_cache_dtype != "auto" else "")
     engine = LLMEngine.from_engine_args(EngineArgs(
-        model=args.model, max_num_seqs=conc, max_model_len=2048, max_num_batched_tokens=args.max_num_batched_tokens,
+        model=args.model, dtype=dtype, quantization=args.quantization, kv_cache_dtype=args.kv_cache_dtype,
+        max_num_seqs=conc, max_model_len=2048, max_num_batched_tokens=args.max_num_batched_tokens,
         num_gpu_blocks_override=int(conc * seq_blocks * 1.25) + 64, swap_space=0.25,
         enforce_eager=args.enforce_eager, max_context_len_to_capture=1024,
         prefill_batch_tokens=args.prefill_batch_tokens, prefill_max_wait=args.prefill_max_wait,
@@ -285,11 +297,11 @@ def main():
 
     good, total, met, seen, ttfts, tpots = loop.goodput_tokens()
     result = {
-        "metric": "goodput (tok/s under TTFT+TBT SLO), Llama-2-7B co-located", "value": round(good / elapsed, 2),
+        "metric": "goodput (tok/s under TTFT+TBT SLO), " + ("Llama-2-7B" if args.model == "llama-2-7b" else args.model) + " co-located", "value": round(good / elapsed, 2),
         "unit": "tok/s", "n_gpus": 1, "steps": args.steps, "warmup": warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": f"{args.model} bf16 co-located on 1 GPU, closed loop with {conc} requests in flight, "
+        "vs_baseline": None, "dtype": dtype_tag, "data": "synthetic",
+        "config": {"workload": f"{args.model} {variant} co-located on 1 GPU, closed loop with {conc} requests in flight, "
                                f"prefill {args.prompt_len} / decode {args.decode_len} tokens, random-init weights, "
                                f"SLO TTFT<={SLO_TTFT}s TPOT<={SLO_TPOT}s",
                    "concurrency": conc, "prompt_len": args.prompt_len, "decode_len": args.decode_len,
