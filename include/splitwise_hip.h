@@ -229,6 +229,26 @@ int sw_awq_gemm(void* c, const void* a, const uint32_t* qweight, const void* sca
 int sw_awq_dequantize(void* out, const uint32_t* qweight, const void* scales,
                       const uint32_t* qzeros, int K, int N, int group_size, void* stream);
 
+/* No counterpart in the reference, which keeps two sets of int4 kernels: an AWQ checkpoint
+ * (csrc/quantization/awq/dequantize.cuh:17-84: a word = 8 columns of one row, columns in the
+ * order 0 2 4 6 1 3 5 7, zeros stored as they are) repacked ONCE into the layout of the GPTQ
+ * kernels after gptq_shuffle (q_gemm.cu:2075, qdq_4.cuh:12-14: a word = 8 consecutive rows of
+ * one column), so that one set of kernels serves both formats.  Out of place:
+ *   qweight_out int32 [K/8, N], qzeros_out int32 [groups, N/8] in plain column order.
+ * The reconstructed fp16 weights are bit-identical to sw_awq_dequantize's.                 */
+int sw_awq_to_kmajor(uint32_t* qweight_out, uint32_t* qzeros_out, const uint32_t* qweight,
+                     const uint32_t* qzeros, int K, int N, int groups, void* stream);
+
+/* sw_gptq_gemm / sw_gptq_dequant on shuffled weights without act-order, with the value added
+ * to the stored zero as an argument: 1 = GPTQ checkpoints (q_gemm.cu:929 `zeros[i] + 1`),
+ * 0 = weights from sw_awq_to_kmajor (dequantize.cuh:60-75 subtracts the zero as stored).   */
+int sw_int4_kmajor_gemm(void* c, const void* a, const uint32_t* qweight, const uint32_t* qzeros,
+                        const void* scales, int M, int N, int K, int groups, int zero_offset,
+                        void* workspace, int64_t workspace_bytes, void* stream);
+int sw_int4_kmajor_dequant(void* out, const uint32_t* qweight, const uint32_t* qzeros,
+                           const void* scales, int K, int N, int groups, int zero_offset,
+                           void* stream);
+
 /* -------------------------------------------- row-wise operators beside the path
  * csrc/layernorm_kernels.cu:70-118 rms_norm / fused_add_rms_norm.
  *   out = (act)(x * rsqrt(mean(x^2) + eps)) * weight, per row of hidden_size elements.

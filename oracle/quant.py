@@ -106,15 +106,17 @@ def _unshuffle_rows(qweight_shuffled: np.ndarray) -> np.ndarray:
     return out.reshape(r * 8, n)
 
 
-def gptq_dequant(qweight: np.ndarray, qzeros: np.ndarray, scales: np.ndarray, g_idx, use_exllama: bool) -> np.ndarray:
-    """fp16 [K, N] in ORIGINAL row order.
+def gptq_dequant(qweight: np.ndarray, qzeros: np.ndarray, scales: np.ndarray, g_idx, use_exllama: bool,
+                 zero_offset: int = 1) -> np.ndarray:
+    """fp16 [K, N] in ORIGINAL row order.  ``zero_offset``: what is added to the stored zero, 1 for
+    GPTQ checkpoints (q_gemm.cu:929); 0 describes AWQ weights repacked into this layout.
     use_exllama: shuffled weights; ``g_idx`` is the row permutation or None; row k' of the
     shuffled matrix belongs to group k' // group_size and lands in output row perm[k']
     (reconstruct_exllama_4bit_kernel, q_gemm.cu:920-1037).
     otherwise: plain weights, ``g_idx[k]`` is the group of row k (reconstruct_gptq_kernel
     :1517-1561)."""
     groups, n = scales.shape
-    zeros = _unpack_cols(qzeros.view(np.uint32), _NATURAL) + 1                  # [G, N]
+    zeros = _unpack_cols(qzeros.view(np.uint32), _NATURAL) + zero_offset        # [G, N]
     if use_exllama:
         q = _unshuffle_rows(qweight)
         k = q.shape[0]

@@ -14,7 +14,8 @@ pytestmark = pytest.mark.gpu
 
 def _dense_state_dict(sd, quantization, shuffled=True):
     """Replaces every int4 linear layer by the fp16 weight the CPU restatement reconstructs from
-    it (GPTQ weights have been shuffled in place by a model's first forward pass)."""
+    it (a model's first forward pass has shuffled GPTQ weights in place and repacked AWQ weights
+    into the same k-major layout)."""
     from oracle import quant
     out = dict(sd)
     for key in sd:
@@ -24,6 +25,8 @@ def _dense_state_dict(sd, quantization, shuffled=True):
         qw, qz, sc = (sd[prefix + n].numpy() for n in ("qweight", "qzeros", "scales"))
         if quantization == "gptq":
             w = quant.gptq_dequant(qw, qz, sc, None, use_exllama=shuffled)
+        elif qw.shape[1] == sc.shape[1]:                     # repacked in place at the first use: k-major words
+            w = quant.gptq_dequant(qw, qz, sc, None, use_exllama=True, zero_offset=0)
         else:
             w = quant.awq_dequantize(qw, sc, qz)
         out[prefix + "weight"] = torch.from_numpy(w.T.copy())          # [out, in] like a dense layer

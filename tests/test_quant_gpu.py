@@ -174,6 +174,52 @@ def test_awq_gemm(m, k, n, group):
     _close(got, quant.awq_gemm(a, qweight, scales, qzeros))
 
 
+@pytest.mark.parametrize("k,n,group", [(128, 64, 32), (512, 320, 64), (1024, 1024, 128)])
+def test_awq_repacked_to_kmajor_reconstructs_the_same_bits(k, n, group):
+    """The one-time repack into the GPTQ kernels' layout loses nothing: the reconstruction from
+    the repacked words equals the CPU restatement of the AWQ reconstruction bit for bit (zeros
+    0 and 15 included: they are stored as they are, no GPTQ -1)."""
+    from splitwise_amd import _C
+    qweight, qzeros, scales = _awq_case(k, n, group, k + n)
+    qw_k, qz_k = _C.ops.awq_to_kmajor(_dev(qweight), _dev(qzeros))
+    assert qw_k.shape == (k // 8, n) and qz_k.shape == (k // group, n // 8)
+    got = _C.ops.int4_kmajor_dequant(qw_k, qz_k, _dev(scales), 0)
+    ref = quant.awq_dequantize(qweight, scales, qzeros)
+    assert np.array_equal(got.cpu().numpy().view(np.uint16), ref.view(np.uint16))
+
+
+@pytest.mark.parametrize("m,k,n,group", [(1, 2560, 5120, 128), (5, 256, 64, 32), (33, 512, 576, 64),
+                                         (100, 1024, 512, 128), (200, 1024, 384, 64), (300, 512, 256, 128)])
+def test_awq_gemm_through_the_kmajor_kernels(m, k, n, group):
+    from splitwise_amd import _C
+    qweight, qzeros, scales = _awq_case(k, n, group, m + k + n)
+    a = np.random.default_rng(m).standard_normal((m, k)).astype(np.float16)
+    qw_k, qz_k = _C.ops.awq_to_kmajor(_dev(qweight), _dev(qzeros))
+    got = _C.ops.int4_kmajor_gemm(_dev(a), qw_k, qz_k, _dev(scales), 0)
+    _close(got, quant.awq_gemm(a, qweight, scales, qzeros))
+
+
+def test_awq_linear_method_repacks_once_and_matches_the_checkpoint_layout_path():
+    from splitwise_amd import _C
+    from splitwise_amd.model_executor.layers.quantization.awq import AWQConfig, AWQLinearMethod
+    k, n, group = 512, 320, 64
+    qweight, qzeros, scales = _awq_case(k, n, group, 7)
+    x = _dev(np.random.default_rng(3).standard_normal((2, 9, k)).astype(np.float16))
+    outs = []
+    for repack in (False, True):
+        method = AWQLinearMethod(AWQConfig(4, group, True), repack=repack)
+        weights = method.create_weights(k, n, k, n, torch.float16)
+        weights = {name: torch.nn.Parameter(_dev(t), requires_grad=False)
+                   for name, t in (("qweight", qweight), ("qzeros", qzeros), ("scales", scales))}
+        outs.append(method.apply_weights(weights, x))
+        again = method.apply_weights(weights, x)
+        assert torch.equal(again, outs[-1])
+        assert bool(weights.get("_kmajor")) == repack
+        assert tuple(weights["qweight"].shape) == ((k // 8, n) if repack else (k, n // 8))
+    assert outs[0].shape == outs[1].shape == (2, 9, n)
+    torch.testing.assert_close(outs[0].float(), outs[1].float(), atol=2e-2, rtol=1e-2)
+
+
 def test_awq_argument_checks_mirror_the_reference():
     from splitwise_amd import _C
     qweight, qzeros, scales = _awq_case(128, 72, 32, 0)               # N = 72 is not a multiple of 64

@@ -124,7 +124,7 @@ template <int MT, int CP, int PF>
 __device__ __forceinline__ void gptq_stream(f32x16 (&acc)[MT][CP], const uint16_t* __restrict__ a,
                                             const uint32_t* __restrict__ qweight, const uint32_t* __restrict__ qzeros,
                                             const uint16_t* __restrict__ scales, int M, int N, int K, int group_size,
-                                            int m0, int ncl, int p_begin, int p_end) {
+                                            int m0, int ncl, int p_begin, int p_end, int zoff) {
   // The unit of streaming is a PAIR of 16-k steps (32 k).  Within a pair the k order is permuted
   // so that a lane's two A fragments are 32 contiguous bytes and the two halves of the wave read
   // the whole 64 bytes of a row: lane (j, half), sub-step i covers k = 32 d + 16 half + 8 i .. + 7,
@@ -179,13 +179,13 @@ __device__ __forceinline__ void gptq_stream(f32x16 (&acc)[MT][CP], const uint16_
       if (d == c_boundary) c_boundary += ppg;
       const uint32_t z = zq[slot] >> zshift;
       if constexpr (CP == 4) {
-        col[0] = gptq_col((z & 0xfu) + 1, (uint16_t)(sq[slot].x & 0xffffu));
-        col[1] = gptq_col(((z >> 4) & 0xfu) + 1, (uint16_t)(sq[slot].x >> 16));
-        col[2] = gptq_col(((z >> 8) & 0xfu) + 1, (uint16_t)(sq[slot].y & 0xffffu));
-        col[3] = gptq_col(((z >> 12) & 0xfu) + 1, (uint16_t)(sq[slot].y >> 16));
+        col[0] = gptq_col((z & 0xfu) + zoff, (uint16_t)(sq[slot].x & 0xffffu));
+        col[1] = gptq_col(((z >> 4) & 0xfu) + zoff, (uint16_t)(sq[slot].x >> 16));
+        col[2] = gptq_col(((z >> 8) & 0xfu) + zoff, (uint16_t)(sq[slot].y & 0xffffu));
+        col[3] = gptq_col(((z >> 12) & 0xfu) + zoff, (uint16_t)(sq[slot].y >> 16));
       } else {
-        col[0] = gptq_col((z & 0xfu) + 1, (uint16_t)(sq[slot] & 0xffffu));
-        col[1] = gptq_col(((z >> 4) & 0xfu) + 1, (uint16_t)(sq[slot] >> 16));
+        col[0] = gptq_col((z & 0xfu) + zoff, (uint16_t)(sq[slot] & 0xffffu));
+        col[1] = gptq_col(((z >> 4) & 0xfu) + zoff, (uint16_t)(sq[slot] >> 16));
       }
     }
 #pragma unroll
@@ -295,7 +295,7 @@ template <int MT, int CP, int PF>
 __global__ void __launch_bounds__(kGemmWaves * 64)
 gptq_gemm_kwaves_kernel(uint16_t* __restrict__ c, const uint16_t* __restrict__ a, const uint32_t* __restrict__ qweight,
                         const uint32_t* __restrict__ qzeros, const uint16_t* __restrict__ scales, int M, int N, int K,
-                        int group_size, int ksplit, int row_tiles, float* __restrict__ partials,
+                        int group_size, int ksplit, int row_tiles, int zoff, float* __restrict__ partials,
                         int32_t* __restrict__ counters) {
   extern __shared__ __attribute__((aligned(16))) float red[];
   __shared__ int s_last;
@@ -312,7 +312,7 @@ gptq_gemm_kwaves_kernel(uint16_t* __restrict__ c, const uint16_t* __restrict__ a
   const int s_begin = (int)((int64_t)pairs * wg / nw), s_end = (int)((int64_t)pairs * (wg + 1) / nw);
 
   f32x16 acc[MT][CP];
-  gptq_stream<MT, CP, PF>(acc, a, qweight, qzeros, scales, M, N, K, group_size, m0, col_ok ? ncol : 0, s_begin, s_end);
+  gptq_stream<MT, CP, PF>(acc, a, qweight, qzeros, scales, M, N, K, group_size, m0, col_ok ? ncol : 0, s_begin, s_end, zoff);
 
   // two passes of 8 accumulator rows; wave w then owns accumulator row 8*pass + w
   float vals[2 * MT][CP];
@@ -358,7 +358,7 @@ template <int MT, int CP>
 __global__ void __launch_bounds__(kGemmWaves * 64)
 gptq_gemm_tiled_kernel(uint16_t* __restrict__ c, const uint16_t* __restrict__ a, const uint32_t* __restrict__ qweight,
                        const uint32_t* __restrict__ qzeros, const uint16_t* __restrict__ scales, int M, int N, int K,
-                       int group_size, int ksplit, int col_tiles, int row_tiles, float* __restrict__ partials,
+                       int group_size, int ksplit, int col_tiles, int row_tiles, int zoff, float* __restrict__ partials,
                        int32_t* __restrict__ counters) {
   using wvec = typename WordVec<CP>::type;
   using svec = typename WordVec<CP>::scale_t;
@@ -452,13 +452,13 @@ gptq_gemm_tiled_kernel(uint16_t* __restrict__ c, const uint16_t* __restrict__ a,
       if (s == c_boundary) c_boundary += spg;
       const uint32_t z = zq[slot] >> zshift;
       if constexpr (CP == 4) {
-        col[0] = gptq_col((z & 0xfu) + 1, (uint16_t)(sq[slot].x & 0xffffu));
-        col[1] = gptq_col(((z >> 4) & 0xfu) + 1, (uint16_t)(sq[slot].x >> 16));
-        col[2] = gptq_col(((z >> 8) & 0xfu) + 1, (uint16_t)(sq[slot].y & 0xffffu));
-        col[3] = gptq_col(((z >> 12) & 0xfu) + 1, (uint16_t)(sq[slot].y >> 16));
+        col[0] = gptq_col((z & 0xfu) + zoff, (uint16_t)(sq[slot].x & 0xffffu));
+        col[1] = gptq_col(((z >> 4) & 0xfu) + zoff, (uint16_t)(sq[slot].x >> 16));
+        col[2] = gptq_col(((z >> 8) & 0xfu) + zoff, (uint16_t)(sq[slot].y & 0xffffu));
+        col[3] = gptq_col(((z >> 12) & 0xfu) + zoff, (uint16_t)(sq[slot].y >> 16));
       } else {
-        col[0] = gptq_col((z & 0xfu) + 1, (uint16_t)(sq[slot] & 0xffffu));
-        col[1] = gptq_col(((z >> 4) & 0xfu) + 1, (uint16_t)(sq[slot] >> 16));
+        col[0] = gptq_col((z & 0xfu) + zoff, (uint16_t)(sq[slot] & 0xffffu));
+        col[1] = gptq_col(((z >> 4) & 0xfu) + zoff, (uint16_t)(sq[slot] >> 16));
       }
     }
     f16x8 af[MT];
@@ -573,7 +573,7 @@ __global__ void permute_columns_kernel(uint16_t* __restrict__ dst, const uint16_
 // one thread: one word row x 4 columns -> 8 rows x 4 fp16
 __global__ void gptq_dequant_kernel(uint16_t* __restrict__ out, const uint32_t* __restrict__ qweight,
                                     const uint32_t* __restrict__ qzeros, const uint16_t* __restrict__ scales,
-                                    const int32_t* __restrict__ g_idx, int K, int N, int group_size, int shuffled) {
+                                    const int32_t* __restrict__ g_idx, int K, int N, int group_size, int shuffled, int zoff) {
   const int n4 = N / 4;
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (int64_t)(K / 8) * n4) return;
@@ -588,7 +588,7 @@ __global__ void gptq_dequant_kernel(uint16_t* __restrict__ out, const uint32_t* 
                             (uint16_t)(s.y >> 16)};
     union { f16x8 f; uint32_t u[4]; } d[4];
 #pragma unroll
-    for (int cc = 0; cc < 4; ++cc) d[cc].f = gptq_dequant8(w[cc], gptq_col(((z >> (4 * cc)) & 0xfu) + 1, sb[cc]));
+    for (int cc = 0; cc < 4; ++cc) d[cc].f = gptq_dequant8(w[cc], gptq_col(((z >> (4 * cc)) & 0xfu) + zoff, sb[cc]));
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int row = g_idx ? g_idx[8 * r + i] : 8 * r + i;     // g_idx holds the row permutation here
@@ -668,6 +668,34 @@ __global__ void awq_dequantize_kernel(uint16_t* __restrict__ out, const uint32_t
   const AwqCols cols = awq_cols(qzeros[(size_t)g * nw + wc],
                                 *reinterpret_cast<const uint4*>(scales + (size_t)g * N + 8 * wc));
   *reinterpret_cast<uint4*>(out + (size_t)k * N + 8 * wc) = awq_dequant8(qweight[idx], cols);
+}
+
+// AWQ checkpoint -> the k-major layout of the GPTQ kernels (a word = 8 consecutive k of one
+// column, even rows in the low half and odd rows in the high half; zeros in plain column order,
+// stored without GPTQ's -1).  One thread per output word.
+__global__ void awq_to_kmajor_kernel(uint32_t* __restrict__ out, const uint32_t* __restrict__ qweight, int k8, int N) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)k8 * N) return;
+  const int r = (int)(idx / N), n = (int)(idx - (int64_t)r * N);
+  const int col = n & 7;
+  const int shift = 4 * ((col >> 1) + 4 * (col & 1));          // nibble of logical column col inside an AWQ word
+  uint32_t w = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const uint32_t q = (qweight[(size_t)(8 * r + i) * (N / 8) + n / 8] >> shift) & 0xfu;
+    w |= q << (4 * (i >> 1) + 16 * (i & 1));
+  }
+  out[idx] = w;
+}
+
+__global__ void awq_zeros_to_kmajor_kernel(uint32_t* __restrict__ out, const uint32_t* __restrict__ qzeros, int64_t words) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= words) return;
+  const uint32_t zw = qzeros[idx];
+  uint32_t w = 0;
+#pragma unroll
+  for (int col = 0; col < 8; ++col) w |= ((zw >> (4 * ((col >> 1) + 4 * (col & 1)))) & 0xfu) << (4 * col);
+  out[idx] = w;
 }
 
 // Fused GEMM, up to 32 rows of A per workgroup.  Grid (column tiles of 256 x row tiles, 1, k splits);
@@ -870,8 +898,9 @@ int sw_gptq_shuffle(uint32_t* qweight, const int32_t* q_perm, int K, int N, int 
   return SW_OK;
 }
 
-int sw_gptq_dequant(void* out, const uint32_t* qweight, const uint32_t* qzeros, const void* scales,
-                    const int32_t* g_idx, int K, int N, int groups, int use_exllama, int bit, void* stream) {
+static int kmajor_dequant(void* out, const uint32_t* qweight, const uint32_t* qzeros, const void* scales,
+                          const int32_t* g_idx, int K, int N, int groups, int use_exllama, int bit, int zoff,
+                          void* stream) {
   SW_CHECK_ARG(bit == 4, "gptq_dequant: only 4-bit weights are supported (got %d)", bit);
   SW_CHECK_ARG(K > 0 && N > 0 && groups > 0 && K % 8 == 0 && N % 8 == 0 && K % groups == 0,
                "gptq_dequant: bad shape K=%d N=%d groups=%d", K, N, groups);
@@ -881,14 +910,19 @@ int sw_gptq_dequant(void* out, const uint32_t* qweight, const uint32_t* qzeros, 
   const int64_t threads = (int64_t)(K / 8) * (N / 4);
   hipLaunchKernelGGL(gptq_dequant_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), static_cast<uint16_t*>(out), qweight, qzeros,
-                     static_cast<const uint16_t*>(scales), g_idx, K, N, group_size, use_exllama ? 1 : 0);
+                     static_cast<const uint16_t*>(scales), g_idx, K, N, group_size, use_exllama ? 1 : 0, zoff);
   SW_CHECK_LAUNCH();
   return SW_OK;
 }
 
-int sw_gptq_gemm(void* c, const void* a, const uint32_t* qweight, const uint32_t* qzeros, const void* scales,
-                 const int32_t* g_idx, int M, int N, int K, int groups, int use_exllama, int bit, void* workspace,
-                 int64_t workspace_bytes, void* stream) {
+int sw_gptq_dequant(void* out, const uint32_t* qweight, const uint32_t* qzeros, const void* scales,
+                    const int32_t* g_idx, int K, int N, int groups, int use_exllama, int bit, void* stream) {
+  return kmajor_dequant(out, qweight, qzeros, scales, g_idx, K, N, groups, use_exllama, bit, 1, stream);
+}
+
+static int kmajor_gemm(void* c, const void* a, const uint32_t* qweight, const uint32_t* qzeros, const void* scales,
+                       const int32_t* g_idx, int M, int N, int K, int groups, int use_exllama, int bit, int zoff,
+                       void* workspace, int64_t workspace_bytes, void* stream) {
   SW_CHECK_ARG(bit == 4, "gptq_gemm: only 4-bit weights are supported (got %d)", bit);
   SW_CHECK_ARG(M >= 0 && N > 0 && K > 0 && groups > 0 && K % 32 == 0 && N % 8 == 0 && K % groups == 0,
                "gptq_gemm: bad shape M=%d N=%d K=%d groups=%d", M, N, K, groups);
@@ -946,7 +980,7 @@ int sw_gptq_gemm(void* c, const void* a, const uint32_t* qweight, const uint32_t
       SW_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                     \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                  \
     hipLaunchKernelGGL(kern, grid, dim3(kGemmWaves * 64), lds, st, out, ap, qweight, qzeros, sp, M, N, K,       \
-                       group_size, ks, col_tiles, row_tiles, partials, counters);                               \
+                       group_size, ks, col_tiles, row_tiles, zoff, partials, counters);                         \
   } while (0)
     if (mt == 1 && cp == 2) SW_GPTQ_TILED(1, 2);
     else if (mt == 1) SW_GPTQ_TILED(1, 4);
@@ -965,7 +999,7 @@ int sw_gptq_gemm(void* c, const void* a, const uint32_t* qweight, const uint32_t
       SW_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                       \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                    \
     hipLaunchKernelGGL(kern, grid, dim3(kGemmWaves * 64), lds, st, out, ap, qweight, qzeros, sp, M, N, K,         \
-                       group_size, ks, row_tiles, partials, counters);                                            \
+                       group_size, ks, row_tiles, zoff, partials, counters);                                      \
   } while (0)
     if (mt == 1 && cp == 2) SW_GPTQ_KWAVES(1, 2, 4);
     else if (mt == 1) SW_GPTQ_KWAVES(1, 4, 4);
@@ -975,6 +1009,44 @@ int sw_gptq_gemm(void* c, const void* a, const uint32_t* qweight, const uint32_t
   }
   SW_CHECK_LAUNCH();
   return SW_OK;
+}
+
+int sw_gptq_gemm(void* c, const void* a, const uint32_t* qweight, const uint32_t* qzeros, const void* scales,
+                 const int32_t* g_idx, int M, int N, int K, int groups, int use_exllama, int bit, void* workspace,
+                 int64_t workspace_bytes, void* stream) {
+  return kmajor_gemm(c, a, qweight, qzeros, scales, g_idx, M, N, K, groups, use_exllama, bit, 1, workspace,
+                     workspace_bytes, stream);
+}
+
+int sw_awq_to_kmajor(uint32_t* qweight_out, uint32_t* qzeros_out, const uint32_t* qweight, const uint32_t* qzeros,
+                     int K, int N, int groups, void* stream) {
+  SW_CHECK_ARG(K > 0 && N > 0 && groups > 0 && K % 8 == 0 && N % 8 == 0, "awq_to_kmajor: bad shape K=%d N=%d groups=%d",
+               K, N, groups);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int64_t words = (int64_t)(K / 8) * N;
+  hipLaunchKernelGGL(awq_to_kmajor_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st, qweight_out, qweight,
+                     K / 8, N);
+  SW_CHECK_LAUNCH();
+  const int64_t zwords = (int64_t)groups * (N / 8);
+  hipLaunchKernelGGL(awq_zeros_to_kmajor_kernel, dim3((unsigned)((zwords + 255) / 256)), dim3(256), 0, st, qzeros_out,
+                     qzeros, zwords);
+  SW_CHECK_LAUNCH();
+  return SW_OK;
+}
+
+int sw_int4_kmajor_gemm(void* c, const void* a, const uint32_t* qweight, const uint32_t* qzeros, const void* scales,
+                        int M, int N, int K, int groups, int zero_offset, void* workspace, int64_t workspace_bytes,
+                        void* stream) {
+  SW_CHECK_ARG(zero_offset == 0 || zero_offset == 1, "int4_kmajor_gemm: zero offset must be 0 or 1 (got %d)", zero_offset);
+  return kmajor_gemm(c, a, qweight, qzeros, scales, nullptr, M, N, K, groups, 1, 4, zero_offset, workspace,
+                     workspace_bytes, stream);
+}
+
+int sw_int4_kmajor_dequant(void* out, const uint32_t* qweight, const uint32_t* qzeros, const void* scales, int K, int N,
+                           int groups, int zero_offset, void* stream) {
+  SW_CHECK_ARG(zero_offset == 0 || zero_offset == 1, "int4_kmajor_dequant: zero offset must be 0 or 1 (got %d)",
+               zero_offset);
+  return kmajor_dequant(out, qweight, qzeros, scales, nullptr, K, N, groups, 1, 4, zero_offset, stream);
 }
 
 int sw_awq_dequantize(void* out, const uint32_t* qweight, const void* scales, const uint32_t* qzeros, int K, int N,

@@ -73,6 +73,10 @@ _SIGNATURES = {
     "sw_gptq_shuffle": [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p],
     "sw_gptq_gemm": [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int,
                      _c_int, _c_int, _c_int, _c_void_p, _c_i64, _c_void_p],
+    "sw_awq_to_kmajor": [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p],
+    "sw_int4_kmajor_gemm": [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_int,
+                            _c_void_p, _c_i64, _c_void_p],
+    "sw_int4_kmajor_dequant": [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_void_p],
     "sw_gptq_dequant": [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int,
                         _c_int, _c_void_p],
     "sw_awq_gemm": [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int,
@@ -623,6 +627,57 @@ def awq_gemm(x: torch.Tensor, qweight: torch.Tensor, scales: torch.Tensor, qzero
     return c
 
 
+def awq_to_kmajor(qweight: torch.Tensor, qzeros: torch.Tensor):
+    """AWQ tensors (qweight [K, N/8], qzeros [groups, N/8]) -> the k-major pair
+    (qweight [K/8, N], qzeros [groups, N/8] in plain column order) that ``int4_kmajor_gemm`` and
+    ``int4_kmajor_dequant`` take with ``zero_offset=0``.  No counterpart in the reference."""
+    _require_cuda(qweight, qzeros)
+    k, n = qweight.size(0), qweight.size(1) * 8
+    if k % 8 != 0:
+        raise RuntimeError(f"awq_to_kmajor: {k} rows are not a multiple of 8")
+    qweight_k = torch.empty((k // 8, n), dtype=torch.int32, device=qweight.device)
+    qzeros_k = torch.empty_like(qzeros)
+    _check(load_library().sw_awq_to_kmajor(qweight_k.data_ptr(), qzeros_k.data_ptr(), qweight.contiguous().data_ptr(),
+                                           qzeros.contiguous().data_ptr(), k, n, qzeros.size(0), _stream(qweight)))
+    return qweight_k, qzeros_k
+
+
+def int4_kmajor_dequant(qweight: torch.Tensor, qzeros: torch.Tensor, scales: torch.Tensor,
+                        zero_offset: int) -> torch.Tensor:
+    """fp16 weight [K, N] of k-major int4 tensors (GPTQ after gptq_shuffle: zero_offset 1; AWQ
+    after awq_to_kmajor: zero_offset 0)."""
+    _require_cuda(qweight, qzeros, scales)
+    _require_half(scales)
+    k, n = qweight.size(0) * 8, qweight.size(1)
+    out = torch.empty((k, n), dtype=torch.float16, device=qweight.device)
+    _check(load_library().sw_int4_kmajor_dequant(out.data_ptr(), qweight.data_ptr(), qzeros.data_ptr(),
+                                                 scales.data_ptr(), k, n, qzeros.size(0), int(zero_offset),
+                                                 _stream(qweight)))
+    return out
+
+
+def int4_kmajor_gemm(a: torch.Tensor, qweight: torch.Tensor, qzeros: torch.Tensor, scales: torch.Tensor,
+                     zero_offset: int) -> torch.Tensor:
+    """a [M, K] fp16 times k-major int4 weights -> [M, N] fp16; above the fused kernels' row limit
+    the weight is reconstructed and a dense GEMM runs, as in ``gptq_gemm``."""
+    _require_cuda(a, qweight, qzeros, scales)
+    _require_half(a, scales)
+    if not a.is_contiguous():
+        a = a.contiguous()
+    m, k = a.shape
+    n = qweight.size(1)
+    if k != qweight.size(0) * 8:
+        raise RuntimeError(f"int4_kmajor_gemm: input has {k} columns, weight has {qweight.size(0) * 8} rows")
+    if m > GPTQ_FUSED_MAX_ROWS:
+        return torch.matmul(a, int4_kmajor_dequant(qweight, qzeros, scales, zero_offset))
+    c = torch.empty((m, n), dtype=torch.float16, device=a.device)
+    ws = _quant_workspace(a, m, n, k)
+    _check(load_library().sw_int4_kmajor_gemm(c.data_ptr(), a.data_ptr(), qweight.data_ptr(), qzeros.data_ptr(),
+                                              scales.data_ptr(), m, n, k, qzeros.size(0), int(zero_offset),
+                                              ws.data_ptr(), ws.numel(), _stream(a)))
+    return c
+
+
 # ------------------------------------------------------------------- cuda_utils
 def get_max_shared_memory_per_block_device_attribute(gpu: int) -> int:
     """``cuda_utils.get_max_shared_memory_per_block_device_attribute``
@@ -645,6 +700,9 @@ ops = SimpleNamespace(
     gptq_gemm=gptq_gemm,
     dequant_gptq=gptq_dequant,
     awq_gemm=awq_gemm,
+    awq_to_kmajor=awq_to_kmajor,
+    int4_kmajor_gemm=int4_kmajor_gemm,
+    int4_kmajor_dequant=int4_kmajor_dequant,
     awq_dequantize=awq_dequantize,
 )
 cache_ops = SimpleNamespace(

@@ -45,8 +45,17 @@ class AWQConfig(QuantizationConfig):
 
 
 class AWQLinearMethod(LinearMethodBase):
-    def __init__(self, quant_config: AWQConfig) -> None:
+    """``repack`` (default on; ``SPLITWISE_AWQ_REPACK=0`` turns it off): at the first use of a layer
+    its checkpoint tensors are rewritten once into the k-major layout of the GPTQ kernels, which
+    then serve it (same fp16 weights bit for bit, a faster path to the matrix cores at every row
+    count).  Like GPTQ's shuffle (gptq.py:205-212) this happens in place: afterwards ``qweight`` is
+    [K/8, N] and ``qzeros`` holds plain column order, and ``weights["_kmajor"]`` is set.  Off, every call goes through ``ops.awq_gemm`` /
+    ``ops.awq_dequantize`` on the checkpoint layout, as in the reference (awq.py:153-172)."""
+
+    def __init__(self, quant_config: AWQConfig, repack: Optional[bool] = None) -> None:
+        import os
         self.quant_config = quant_config
+        self.repack = os.environ.get("SPLITWISE_AWQ_REPACK", "1") != "0" if repack is None else bool(repack)
 
     def create_weights(self, input_size_per_partition: int, output_size_per_partition: int, input_size: int,
                        output_size: int, params_dtype: torch.dtype) -> Dict[str, Any]:
@@ -73,8 +82,16 @@ class AWQLinearMethod(LinearMethodBase):
                       bias: Optional[torch.Tensor] = None) -> torch.Tensor:
         qweight, scales, qzeros = weights["qweight"], weights["scales"], weights["qzeros"]
         pack_factor = self.quant_config.pack_factor
-        out_shape = x.shape[:-1] + (qweight.shape[-1] * pack_factor,)
         reshaped_x = x.reshape(-1, x.shape[-1])
+        if self.repack and x.is_cuda:
+            if not weights.get("_kmajor"):
+                qweight.data, qzeros.data = _C.ops.awq_to_kmajor(qweight.data, qzeros.data)
+                weights["_kmajor"] = True
+            out = _C.ops.int4_kmajor_gemm(reshaped_x, qweight, qzeros, scales, 0)
+            if bias is not None:
+                out = out + bias
+            return out.reshape(x.shape[:-1] + (qweight.shape[-1],))
+        out_shape = x.shape[:-1] + (qweight.shape[-1] * pack_factor,)
         if x.shape[:-1].numel() >= 256:                   # many tokens: dense GEMM on the fp16 weight
             out = torch.matmul(reshaped_x, _C.ops.awq_dequantize(qweight, scales, qzeros, 0, 0, 0))
         else:
