@@ -59,7 +59,15 @@ class CacheEngine:
         kshape, vshape = self.get_key_block_shape(), self.get_value_block_shape()
         block_elems = self.num_heads * self.head_size * self.block_size
         offsets, _, total = slab_layout(self.num_layers, block_elems * es, num_blocks)
-        slab = torch.empty(total, dtype=torch.uint8, device=device)
+        # A device allocation of its own, never a piece of a segment the caching allocator has kept
+        # from earlier tensors: the paired worker maps the allocation the slab lives in, and only
+        # the size slab_layout() chose is known to be mappable.
+        if device.type == "cuda":
+            self._slab_pool = torch.cuda.MemPool()
+            with torch.cuda.use_mem_pool(self._slab_pool, device=device):
+                slab = torch.empty(total, dtype=torch.uint8, device=device)
+        else:
+            slab = torch.empty(total, dtype=torch.uint8, device=device)
         self.gpu_slab = slab
         n = num_blocks * block_elems * es
         cache: List[KVCache] = []
