@@ -158,13 +158,27 @@ paged_attention_kernel(void* __restrict__ out_,            // v1: [S,H,HEAD]; v2
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int seq = blockIdx.y;
+  // Workgroups go to the 8 XCDs round robin in launch order.  All head groups of a sequence walk
+  // the same block table and the same cache blocks (a block holds its heads side by side), so
+  // they are renumbered to run on ONE XCD, next to each other in time: its L2 and its address
+  // translation then see each block of the sequence once, not once per XCD (2-3 % on launches
+  // of thousands of workgroups; small launches keep the plain order).
+  int seq = blockIdx.y, hx = blockIdx.x;
+  {
+    const int total = gridDim.x * gridDim.y;
+    if ((total & 7) == 0 && total >= 1024) {
+      const int lin = blockIdx.y * gridDim.x + blockIdx.x;
+      const int work = (lin & 7) * (total >> 3) + (lin >> 3);
+      seq = work / (int)gridDim.x;
+      hx = work - seq * (int)gridDim.x;
+    }
+  }
   const int part_idx = blockIdx.z;
   const int num_parts = gridDim.z;
   const int groups_per_kv = num_heads / num_kv_heads;       // query heads per kv head
   const int wg_per_kv = groups_per_kv / QG;
-  const int kv_head = blockIdx.x / wg_per_kv;
-  const int head0 = kv_head * groups_per_kv + (blockIdx.x - kv_head * wg_per_kv) * QG;
+  const int kv_head = hx / wg_per_kv;
+  const int head0 = kv_head * groups_per_kv + (hx - kv_head * wg_per_kv) * QG;
 
   const int ctx = context_lens[seq];
   const int tok_begin = partitioned ? part_idx * kPartitionSize : 0;
