@@ -43,6 +43,9 @@ typedef enum sw_dtype {
 } sw_dtype;
 
 const char* sw_last_error(void);
+/* Version of this interface; sw_abi_version() returns the one the library was built from.
+ * 2: sw_awq_to_kmajor, sw_int4_kmajor_gemm, sw_int4_kmajor_dequant added. */
+#define SW_ABI_VERSION 2
 int sw_abi_version(void);
 
 /* csrc/cuda_utils_kernels.cu:16-35 get_max_shared_memory_per_block_device_attribute:

@@ -37,7 +37,9 @@ def test_python_binding_covers_the_header():
     from splitwise_amd import _C
     assert sorted(_C.exported_symbols()) == declared_symbols()
     lib = _C.load_library()
-    assert lib.sw_abi_version() >= 1
+    header = open(HEADER).read()
+    declared = int(re.search(r"#define SW_ABI_VERSION (\d+)", header).group(1))
+    assert lib.sw_abi_version() == declared == _C.ABI_VERSION
 
 
 @pytest.mark.skipif(not os.path.exists(LIB), reason="library not built")

@@ -92,8 +92,12 @@ def library_path() -> str:
     return _LIB_PATH
 
 
+ABI_VERSION = 2                # SW_ABI_VERSION of include/splitwise_hip.h this binding was written against
+
+
 def load_library() -> ctypes.CDLL:
-    """Loads the native library once; raises RuntimeError when it is absent."""
+    """Loads the native library once; raises RuntimeError when it is absent or was built from
+    another version of the interface."""
     global _lib
     if _lib is not None:
         return _lib
@@ -104,6 +108,10 @@ def load_library() -> ctypes.CDLL:
     lib = ctypes.CDLL(_LIB_PATH)
     lib.sw_last_error.restype = ctypes.c_char_p
     lib.sw_last_error.argtypes = []
+    lib.sw_abi_version.argtypes, lib.sw_abi_version.restype = [], _c_int
+    if lib.sw_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"{_LIB_PATH} implements interface version {lib.sw_abi_version()}, this binding needs "
+                           f"{ABI_VERSION}: rebuild it (`make -C vllm-splitwise_amd`)")
     for name, argtypes in _SIGNATURES.items():
         fn = getattr(lib, name)
         fn.argtypes = argtypes
