@@ -87,14 +87,17 @@ def main():
     ap.add_argument("--prefill-batch-tokens", type=int, default=2300)
     ap.add_argument("--prefill-max-wait", type=float, default=0.08)
     ap.add_argument("--no-pipeline-steps", action="store_true")
+    ap.add_argument("--quantization", default=None, choices=[None, "gptq", "awq"])
+    ap.add_argument("--kv-cache-dtype", default="auto", choices=["auto", "fp8_e5m2"])
     args = ap.parse_args()
 
     from splitwise_amd import EngineArgs, LLMEngine
     torch.cuda.set_device(0)
     np.random.seed(0)
     seq_blocks = -(-(args.prompt_len + args.decode_len + 1) // 16)
+    dtype = "float16" if args.quantization else "bfloat16"
     engine = LLMEngine.from_engine_args(EngineArgs(
-        model=args.model, max_num_seqs=args.max_num_seqs, max_model_len=2048, max_num_batched_tokens=4096,
+        model=args.model, dtype=dtype, quantization=args.quantization, kv_cache_dtype=args.kv_cache_dtype, max_num_seqs=args.max_num_seqs, max_model_len=2048, max_num_batched_tokens=4096,
         num_gpu_blocks_override=int(args.max_num_seqs * seq_blocks * 1.25) + 64, swap_space=0.25,
         max_context_len_to_capture=1024, prefill_batch_tokens=args.prefill_batch_tokens,
         prefill_max_wait=args.prefill_max_wait, pipeline_steps=not args.no_pipeline_steps))
@@ -104,7 +107,9 @@ def main():
         n = int(min(max(100, rate * args.seconds), 600))
         res = run_rate(engine, rate, n, args.prompt_len, args.decode_len, args.temperature, first_id)
         first_id += n
-        res["config"] = f"{args.model} bf16 co-located, 1 GPU, prefill {args.prompt_len} / decode {args.decode_len}"
+        res["config"] = (f"{args.model} {dtype}" + (f" {args.quantization} int4" if args.quantization else "") +
+                         (" fp8 KV cache" if args.kv_cache_dtype != "auto" else "") +
+                         f" co-located, 1 GPU, prefill {args.prompt_len} / decode {args.decode_len}")
         print(json.dumps(res), flush=True)
 
 
