@@ -52,17 +52,24 @@ class PagedAttentionImpl:
         """The unpartitioned kernel launches one workgroup per (sequence, group of ``query_group``
         query heads); it fills the 256 CUs only with enough of them, below that the context is
         split into 512-token partitions (v2).  Thresholds measured on MI355X for MHA, GQA and fp8
-        shapes (1..256 sequences, 768..16384 tokens).  (The reference's rule, ops/paged_attn.py:62-63,
+        shapes (1..256 sequences, 768..16384 tokens; within 1 % of the better kernel summed over that sweep,
+        at most 18 % off in any one case).  (The reference's rule, ops/paged_attn.py:62-63,
         is tuned for 128-thread blocks per query head and a shared-memory cap that does not exist
         here.)"""
         if max_context_len <= _PARTITION_SIZE:
             return True
         workgroups = num_seqs * num_heads // max(query_group, 1)
+        if query_group >= 4:
+            # a workgroup that serves 4 or 8 query heads is dot-product bound and long-running:
+            # partitions pay until the launch fills every compute unit twice over
+            return workgroups >= 512
         if workgroups >= 512:
             return True
-        if workgroups >= 256 and max_context_len < 4096:
-            return True
-        return workgroups >= 32 and max_context_len <= 2 * _PARTITION_SIZE
+        if workgroups >= 256:
+            return max_context_len < 4096
+        if workgroups >= 128:
+            return max_context_len <= _PARTITION_SIZE + _PARTITION_SIZE // 2
+        return workgroups >= 16 and max_context_len <= 2 * _PARTITION_SIZE
 
     @staticmethod
     def forward_prefix(query, key, value, key_cache, value_cache, input_metadata: InputMetadata,
