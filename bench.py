@@ -16,6 +16,14 @@ prompt and 170 generated tokens -- the mean request shape of the reference's own
 logs.  Goodput counts the tokens generated inside the timed region by requests that meet
 the reference's SLO (TTFT <= 0.25 s and mean time between tokens <= 0.1 s).
 
+The run has three phases.  FILL (untimed, independent of --warmup): one request is admitted per
+step until C are in flight, then the loop runs on until every request of that first cohort --
+whose lengths are randomised so that completions do not come in bursts -- has finished; from
+then on every live request has the full shape and the batch is in steady state.  WARMUP: W
+more untimed steps.  TIMED: exactly K steps between device synchronisations.  What the timed
+region actually held (live requests, decode batch sizes, prompt / decode steps) is printed in
+`config`, measured, next to what was asked for.
+
 The JSON line also carries
   roofline      decode paged attention (the dominant, HBM-bound kernel): algorithmic KV bytes
                 per launch / average launch time, timed with HIP events on the launch stream
@@ -48,7 +56,9 @@ def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=600)
-    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=20, help="untimed steps after the fill phase")
+    ap.add_argument("--no-fill", action="store_true",
+                    help="skip the fill phase (the timed region then starts on a ramp, and says so)")
     ap.add_argument("--concurrency", type=int, default=256, help="requests kept in flight per replica")
     ap.add_argument("--model", default="llama-2-7b")
     ap.add_argument("--prompt-len", type=int, default=PROMPT_LEN)
@@ -85,6 +95,9 @@ class ClosedLoop:
         self.ramp = 0
         self.req = {}                # request id -> dict(arrival, first, last, n, window_tokens)
         self.step_kinds = {True: [0, 0.0], False: [0, 0.0]}     # prompt_run -> [steps, seconds] in window
+        self.first_cohort_live = 0   # requests of the randomised first cohort not finished yet
+        self.live_in_window = []     # requests in flight at the start of every timed step
+        self.fill_steps = 0
 
     def _add(self, now):
         from splitwise_amd import SamplingParams
@@ -100,6 +113,8 @@ class ClosedLoop:
         self.engine.add_request(rid, None, params, prompt_token_ids=prompt)
         self.req[rid] = dict(arrival=now, first=None, last=None, n=0, window=0)
         self.live += 1
+        if self.next_id <= self.concurrency:
+            self.first_cohort_live += 1
 
     def feed(self):
         """One new request per step while ramping up (so no request queues behind a burst),
@@ -111,8 +126,30 @@ class ClosedLoop:
         while self.live < min(self.ramp, self.concurrency):
             self._add(now)
 
+    def steady(self):
+        """Every slot is taken by a full-length request: the ramp is over and the randomised
+        first cohort has drained."""
+        return self.ramp >= self.concurrency and self.first_cohort_live == 0
+
+    def fill(self, progress=None):
+        """Untimed fill phase: steps until steady() holds (bounded, so a stuck engine cannot
+        spin here for ever).  Returns whether steady state was reached."""
+        limit = 8 * self.concurrency + 4 * self.params.max_tokens + 200
+        while not self.steady() and self.fill_steps < limit:
+            self.step(False)
+            self.fill_steps += 1
+            if progress is not None and self.fill_steps % 50 == 0:
+                progress(self.fill_steps, self.live)
+        return self.steady()
+
+    def window_stats(self):
+        lv = self.live_in_window
+        return {"live_min": min(lv) if lv else 0, "live_mean": round(sum(lv) / max(len(lv), 1), 1)}
+
     def step(self, in_window):
         self.feed()
+        if in_window:
+            self.live_in_window.append(self.live)
         t_begin = time.perf_counter()
         had_waiting = bool(self.engine.scheduler.waiting)
         outs = self.engine.step()
@@ -135,6 +172,8 @@ class ClosedLoop:
                 r["last"] = now
             if out.finished:
                 self.live -= 1
+                if int(out.request_id) < self.concurrency:
+                    self.first_cohort_live -= 1
         return new_tokens
 
     def goodput_tokens(self):
@@ -199,25 +238,27 @@ def measure_attention_roofline(engine, samples):
            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
            "avg_launch_us": round(avg_s * 1e6, 2), "launches_timed": launches,
            "alg_bytes_per_launch": int(alg_bytes / launches)}
-    pmc = pmc_traffic()
-    # the counter summary belongs to the workload it was collected on
-    if pmc and abs(pmc["traffic_alg_bytes_per_launch"] - out["alg_bytes_per_launch"]) <= 0.05 * out["alg_bytes_per_launch"]:
-        out.update(pmc)
+    out.update(pmc_traffic(out["alg_bytes_per_launch"]))
     return out
 
 
-def pmc_traffic():
-    """HBM bytes per launch of the same kernel from hardware counters.  Counters cannot be read
-    from inside this process: tools/pmc_traffic.sh runs this very command under rocprofv3 --pmc
-    (one pass per counter) and tools/pmc_traffic.py averages the LAST `launches_timed` dispatches
-    of the kernel -- the timed launches above -- into the summary read here."""
-    path = os.environ.get("SPLITWISE_PMC_SUMMARY", os.path.join(os.path.dirname(os.path.abspath(__file__)),
-                                                                "profiles", "r1", "pmc_paged_attention.json"))
+def pmc_traffic(alg_bytes_per_launch):
+    """HBM bytes per launch of the same kernel from hardware counters.  Counters cannot be read from
+    inside this process, so `traffic` is null in an ordinary run.  tools/pmc_traffic.sh runs this very
+    command under rocprofv3 --pmc (one pass per counter), averages the last `launches_timed` dispatches
+    of the kernel -- the timed launches above -- into a summary and re-runs the command with
+    SPLITWISE_PMC_SUMMARY pointing at it: only then, and only when the summary was collected on the
+    same algorithmic bytes per launch (5 %), is `traffic` filled, with its source beside it."""
+    path = os.environ.get("SPLITWISE_PMC_SUMMARY")
+    if not path:
+        return {}
     try:
         with open(path) as f:
             pmc = json.load(f)
+        if abs(int(pmc["alg_bytes_per_launch"]) - alg_bytes_per_launch) > 0.05 * alg_bytes_per_launch:
+            return {"traffic_note": "offline counter summary belongs to another workload; ignored"}
         return {"traffic": int(pmc["traffic_bytes_per_launch"]), "traffic_unit": "bytes/launch",
-                "traffic_source": os.path.relpath(path, os.path.dirname(os.path.abspath(__file__))),
+                "traffic_source": "offline rocprofv3 --pmc passes of this command: " + os.path.basename(path),
                 "traffic_alg_bytes_per_launch": int(pmc["alg_bytes_per_launch"])}
     except (OSError, KeyError, ValueError):
         return {}
@@ -245,7 +286,7 @@ def main():
     from splitwise_amd import EngineArgs, LLMEngine
     torch.cuda.set_device(0)
     conc = args.concurrency
-    warmup = args.warmup if args.warmup is not None else 3 * conc
+    warmup = args.warmup
     seq_blocks = -(-(args.prompt_len + args.decode_len + 1) // 16)
     dtype = args.dtype or ("float16" if args.quantization else "bfloat16")
     dtype_tag = {"bfloat16": "bf16", "float16": "f16", "half": "f16", "float32": "f32"}.get(dtype, dtype)
@@ -260,29 +301,36 @@ def main():
         pipeline_steps=not args.no_pipeline_steps))
     loop = ClosedLoop(engine, conc, args.prompt_len, args.decode_len, seed=0)
 
-    # sample decode batches of the timed region for the roofline measurement (references only)
+    # decode batches of the timed region: their sizes (all of them) and, for the roofline
+    # measurement, the block tables and context lengths of up to 12 spread over the region
     runner = engine.model_executor.driver_worker.model_runner
     samples = []
+    batch_sizes = []
     orig_prepare = runner._prepare_decode
     state = {"on": False, "count": 0}
+    stride = max(1, args.steps // 24)
 
     def sampling_prepare(metas):
         out = orig_prepare(metas)
         if state["on"]:
-            state["count"] += 1
-            if state["count"] % 16 == 1 and len(samples) < 12:
-                md = out[2]
-                n = sum(len(m.seq_data) for m in metas)
+            n = sum(len(m.seq_data) for m in metas)
+            batch_sizes.append(n)
+            if state["count"] % stride == 0 and len(samples) < 12:
                 import copy
+                md = out[2]
                 keep = copy.copy(md)
                 keep.context_lens = md.context_lens[:n].clone()
                 keep.block_tables = md.block_tables[:n].clone()
                 keep.max_context_len = md.max_context_len
                 samples.append(keep)
+            state["count"] += 1
         return out
 
     runner._prepare_decode = sampling_prepare
 
+    steady = True
+    if not args.no_fill:
+        steady = loop.fill()
     for _ in range(warmup):
         loop.step(False)
     torch.cuda.synchronize()
@@ -296,15 +344,25 @@ def main():
     state["on"] = False
 
     good, total, met, seen, ttfts, tpots = loop.goodput_tokens()
+    win = loop.window_stats()
+    in_flight = win["live_min"] if win["live_min"] >= 0.95 * conc else win["live_mean"]
+    state_tag = "steady state" if (steady and not args.no_fill and win["live_min"] >= 0.95 * conc) else \
+        "RAMP (not steady state)"
     result = {
         "metric": "goodput (tok/s under TTFT+TBT SLO), " + ("Llama-2-7B" if args.model == "llama-2-7b" else args.model) + " co-located", "value": round(good / elapsed, 2),
         "unit": "tok/s", "n_gpus": 1, "steps": args.steps, "warmup": warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": dtype_tag, "data": "synthetic",
-        "config": {"workload": f"{args.model} {variant} co-located on 1 GPU, closed loop with {conc} requests in flight, "
+        "config": {"workload": f"{args.model} {variant} co-located on 1 GPU, closed loop, {state_tag}: {in_flight:g} requests "
+                               f"in flight over the timed steps ({conc} asked for), "
                                f"prefill {args.prompt_len} / decode {args.decode_len} tokens, random-init weights, "
                                f"SLO TTFT<={SLO_TTFT}s TPOT<={SLO_TPOT}s",
-                   "concurrency": conc, "prompt_len": args.prompt_len, "decode_len": args.decode_len,
+                   "concurrency": in_flight, "concurrency_target": conc,
+                   "live_min": win["live_min"], "live_mean": win["live_mean"],
+                   "decode_batch_min": min(batch_sizes) if batch_sizes else 0,
+                   "decode_batch_mean": round(sum(batch_sizes) / max(len(batch_sizes), 1), 1),
+                   "fill_steps": loop.fill_steps, "steady_state": state_tag == "steady state",
+                   "prompt_len": args.prompt_len, "decode_len": args.decode_len,
                    "prefill_batch_tokens": args.prefill_batch_tokens, "prefill_max_wait_s": args.prefill_max_wait,
                    "hip_graphs": not args.enforce_eager, "pipeline_steps": not args.no_pipeline_steps},
         "throughput_tok_s": round(total / elapsed, 2),

@@ -101,21 +101,27 @@ def _run(args, rank: int, local_rank: int, world: int) -> None:
                                  channel=DistChannel(rank + 1), prompt_device=local_rank, transport=transport)
     engine = LLMEngine(mc, cc, pc, sc, dc, executor=executor)
     loop = bench_main.ClosedLoop(engine, conc, args.prompt_len, args.decode_len, seed=rank)
-    warmup = args.warmup if args.warmup is not None else 3 * conc
+    warmup = args.warmup
     import sys
     verbose = os.environ.get("SPLITWISE_BENCH_VERBOSE") == "1"
+
+    def progress(step, live):
+        if verbose:
+            print(f"[rank {rank}] fill step {step} live={live}", file=sys.stderr, flush=True)
+
+    # untimed fill phase, independent of --warmup: until every slot holds a full-length request
+    steady = True if getattr(args, "no_fill", False) else loop.fill(progress)
     for i in range(warmup):
         loop.step(False)
-        if verbose and i % 20 == 0:
-            print(f"[rank {rank}] warmup step {i} live={loop.live}", file=sys.stderr, flush=True)
     torch.cuda.synchronize()
     if engines is not None:
         dist.barrier(group=engines)
     t0 = time.perf_counter()
     ctx_samples = []
+    stride = max(1, args.steps // 12)
     for i in range(args.steps):
         loop.step(True)
-        if i % 16 == 8 and len(ctx_samples) < 12:           # decode batches of the timed region, for the roofline
+        if i % stride == stride // 2 and len(ctx_samples) < 12:           # decode batches of the timed region, for the roofline
             lens = [g.get_seqs()[0].get_len() for g in engine.scheduler.running if g.get_seqs()[0].get_output_len() > 0]
             if lens:
                 ctx_samples.append(lens)
@@ -129,11 +135,15 @@ def _run(args, rank: int, local_rank: int, world: int) -> None:
     elapsed = time.perf_counter() - t0
 
     good, total, met, seen, ttfts, tpots = loop.goodput_tokens()
-    stats = torch.tensor([good, total, met, seen, executor.kv_bytes_pushed()], dtype=torch.float64)
+    win = loop.window_stats()
+    steady = bool(steady and not getattr(args, "no_fill", False) and win["live_min"] >= 0.95 * conc)
+    stats = torch.tensor([good, total, met, seen, executor.kv_bytes_pushed(), win["live_mean"]], dtype=torch.float64)
     tmax = torch.tensor([elapsed], dtype=torch.float64)
+    tmin = torch.tensor([float(win["live_min"]), float(steady)], dtype=torch.float64)
     if engines is not None:
         dist.all_reduce(stats, group=engines)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX, group=engines)
+        dist.all_reduce(tmin, op=dist.ReduceOp.MIN, group=engines)
     kv = _kv_push_bandwidth(executor)
     roofline = None
     if rank == 0 and ctx_samples:
@@ -151,24 +161,31 @@ def _run(args, rank: int, local_rank: int, world: int) -> None:
     if rank == 0:
         elapsed = float(tmax.item())
         pairs = world // 2
+        live_min, steady_all = int(tmin[0].item()), bool(tmin[1].item())
+        live_mean = round(float(stats[5]) / pairs, 1)
+        in_flight = live_min if live_min >= 0.95 * conc else live_mean
+        state_tag = "steady state" if steady_all else "RAMP (not steady state)"
         result = {
             "metric": "goodput (tok/s under TTFT+TBT SLO), Llama-2-7B split 1P+1D per pair",
             "value": round(float(stats[0]) / elapsed, 2), "unit": "tok/s", "n_gpus": world, "steps": args.steps,
             "warmup": warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"{args.model} bf16, {pairs} independent pair(s) of 1 prompt GPU + 1 token GPU, "
-                                   f"KV blocks pushed prompt->token over xGMI ({transport} transport), closed loop "
-                                   f"with {conc} requests in flight per pair, prefill {args.prompt_len} / decode "
+                                   f"KV blocks pushed prompt->token over xGMI ({transport} transport), closed loop, "
+                                   f"{state_tag}: {in_flight:g} requests in flight per pair over the timed steps "
+                                   f"({conc} asked for), prefill {args.prompt_len} / decode "
                                    f"{args.decode_len} tokens, random-init weights, SLO TTFT<={bench_main.SLO_TTFT}s "
                                    f"TPOT<={bench_main.SLO_TPOT}s",
-                       "parallelism": f"{pairs}x(1P+1D)", "concurrency_per_pair": conc,
+                       "parallelism": f"{pairs}x(1P+1D)", "concurrency_per_pair": in_flight,
+                       "concurrency_target": conc, "live_min": live_min, "live_mean": live_mean,
+                       "fill_steps": loop.fill_steps, "steady_state": steady_all,
                        "pipeline_steps": bool(engine.pipeline_split)},
             "throughput_tok_s": round(float(stats[1]) / elapsed, 2),
             "slo_attainment": round(float(stats[2]) / max(float(stats[3]), 1.0), 4),
             "kv_bytes_pushed": int(stats[4]),
             "kv_migration": kv,
             "roofline": roofline,
-            "cpu_baseline": None,
+            "cpu_baseline": None,             # timed at N=1 only (one bounded CPU sample per round is enough)
             "ttft_p50_ms": round(sorted(ttfts)[len(ttfts) // 2] * 1e3, 2) if ttfts else None,
             "tpot_p50_ms": round(sorted(tpots)[len(tpots) // 2] * 1e3, 2) if tpots else None,
         }
