@@ -44,8 +44,9 @@ typedef enum sw_dtype {
 
 const char* sw_last_error(void);
 /* Version of this interface; sw_abi_version() returns the one the library was built from.
- * 2: sw_awq_to_kmajor, sw_int4_kmajor_gemm, sw_int4_kmajor_dequant added. */
-#define SW_ABI_VERSION 2
+ * 2: sw_awq_to_kmajor, sw_int4_kmajor_gemm, sw_int4_kmajor_dequant added.
+ * 3: sw_paged_attention_v2_static, sw_paged_attention_v2_static_max_bytes added. */
+#define SW_ABI_VERSION 3
 int sw_abi_version(void);
 
 /* csrc/cuda_utils_kernels.cu:16-35 get_max_shared_memory_per_block_device_attribute:
@@ -127,6 +128,30 @@ int sw_paged_attention_v2(void* out, float* exp_sums, float* max_logits,
                           const float* alibi_slopes, int64_t q_stride,
                           int64_t kv_block_stride, int64_t kv_head_stride,
                           int act_dtype, int cache_dtype, void* stream);
+
+/* No counterpart in the reference (whose caller allocates the three temporaries on every call,
+ * vllm/model_executor/layers/attention/ops/paged_attn.py:83-93).  For callers that cannot
+ * allocate device memory -- code under HIP graph capture, tight serving loops, harnesses that
+ * forbid hipMalloc: sw_paged_attention_v2 with exp_sums / max_logits / tmp_out taken from a
+ * file-scope device array of sw_paged_attention_v2_static_max_bytes() = 32 MiB that every GPU the
+ * library runs on holds until the process ends.  Allocates nothing, on the host side neither.
+ * Rejected with SW_ERR_INVALID when
+ *   2 * round256(4 * R) + round256(R * head_size * sizeof(act)) > 32 MiB,
+ *   R = num_seqs * num_heads * ceil(max_context_len / 512)
+ * (e.g. 256 sequences x 32 heads x 1024 tokens x 128 bf16: 4.3 MiB).  Results are bit-identical to
+ * sw_paged_attention_v2's.  Every call on one GPU uses that GPU's one array: calls that overlap
+ * on a GPU (two streams, two threads) race; order them on one stream.  Nothing in the array has
+ * to be zero: each call writes every row it later reads.                                     */
+int64_t sw_paged_attention_v2_static_max_bytes(void);
+int sw_paged_attention_v2_static(void* out, const void* query, const void* key_cache,
+                                 const void* value_cache, int num_seqs, int num_heads,
+                                 int num_kv_heads, int head_size, float scale,
+                                 const int32_t* block_tables,
+                                 const int32_t* context_lens, int block_size,
+                                 int max_context_len, int max_num_blocks_per_seq,
+                                 const float* alibi_slopes, int64_t q_stride,
+                                 int64_t kv_block_stride, int64_t kv_head_stride,
+                                 int act_dtype, int cache_dtype, void* stream);
 
 /* ---------------------------------------------------------- prefill attention
  * Causal self-attention of a prompt run.  Replaces the prompt branch of the

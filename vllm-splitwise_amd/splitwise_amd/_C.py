@@ -46,6 +46,10 @@ _SIGNATURES = {
                               _c_int, _c_int, _c_int, _c_int, _c_float, _c_void_p, _c_void_p, _c_int,
                               _c_int, _c_int, _c_void_p, _c_i64, _c_i64, _c_i64, _c_int, _c_int,
                               _c_void_p],
+    "sw_paged_attention_v2_static_max_bytes": [],
+    "sw_paged_attention_v2_static": [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int,
+                                     _c_float, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p,
+                                     _c_i64, _c_i64, _c_i64, _c_int, _c_int, _c_void_p],
     "sw_prefill_attention": [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int,
                              _c_int, _c_int, _c_int, _c_float, _c_void_p, _c_i64, _c_i64, _c_i64, _c_i64,
                              _c_int, _c_int, _c_void_p],
@@ -83,7 +87,8 @@ _SIGNATURES = {
                     _c_void_p, _c_i64, _c_void_p],
     "sw_awq_dequantize": [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p],
 }
-_RESTYPES = {"sw_quant_gemm_workspace_bytes": _c_i64, "sw_custom_ar_signal_bytes": _c_i64}     # everything else returns an int status
+_RESTYPES = {"sw_quant_gemm_workspace_bytes": _c_i64, "sw_custom_ar_signal_bytes": _c_i64,
+             "sw_paged_attention_v2_static_max_bytes": _c_i64}     # everything else returns an int status
 
 _lib = None
 
@@ -92,7 +97,7 @@ def library_path() -> str:
     return _LIB_PATH
 
 
-ABI_VERSION = 2                # SW_ABI_VERSION of include/splitwise_hip.h this binding was written against
+ABI_VERSION = 3                # SW_ABI_VERSION of include/splitwise_hip.h this binding was written against
 
 
 def load_library() -> ctypes.CDLL:
@@ -304,6 +309,28 @@ def paged_attention_v2(out: torch.Tensor, exp_sums: torch.Tensor, max_logits: to
             query.data_ptr(), key_cache.data_ptr(), value_cache.data_ptr(), num_seqs, num_heads,
             num_kv_heads, head_size, float(scale), block_tables.data_ptr(), context_lens.data_ptr(),
             block_size, int(max_context_len), block_tables.stride(0),
+            alibi_slopes.data_ptr() if alibi_slopes is not None else None, query.stride(0),
+            key_cache.stride(0), key_cache.stride(1), act, cache, _stream(query)))
+
+
+def paged_attention_v2_static(out: torch.Tensor, query: torch.Tensor, key_cache: torch.Tensor,
+                              value_cache: torch.Tensor, num_kv_heads: int, scale: float,
+                              block_tables: torch.Tensor, context_lens: torch.Tensor, block_size: int,
+                              max_context_len: int, alibi_slopes: Optional[torch.Tensor],
+                              kv_cache_dtype: str) -> None:
+    """``paged_attention_v2`` without the three temporaries: they live in the library's static device
+    scratch (32 MiB per GPU), so the call allocates nothing.  The argument list is
+    ``paged_attention_v1``'s.  Raises RuntimeError when the temporaries would not fit; calls on one
+    GPU must not overlap."""
+    alibi_slopes = _pa_common(query, key_cache, value_cache, block_tables, context_lens, alibi_slopes)
+    act = _act_dtype(query)
+    cache = _cache_dtype(kv_cache_dtype, act)
+    num_seqs, num_heads, head_size = query.shape
+    with torch.cuda.device(query.device):
+        _check(load_library().sw_paged_attention_v2_static(
+            out.data_ptr(), query.data_ptr(), key_cache.data_ptr(), value_cache.data_ptr(),
+            num_seqs, num_heads, num_kv_heads, head_size, float(scale), block_tables.data_ptr(),
+            context_lens.data_ptr(), block_size, int(max_context_len), block_tables.stride(0),
             alibi_slopes.data_ptr() if alibi_slopes is not None else None, query.stride(0),
             key_cache.stride(0), key_cache.stride(1), act, cache, _stream(query)))
 
@@ -698,6 +725,7 @@ def get_max_shared_memory_per_block_device_attribute(gpu: int) -> int:
 ops = SimpleNamespace(
     paged_attention_v1=paged_attention_v1,
     paged_attention_v2=paged_attention_v2,
+    paged_attention_v2_static=paged_attention_v2_static,
     prefill_attention=prefill_attention,
     context_attention_fwd=context_attention_fwd,
     rms_norm=rms_norm,
