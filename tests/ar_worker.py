@@ -22,14 +22,14 @@ def _input(rank: int, case: int, numel: int, dtype):
     return (torch.randn(numel, generator=g) * 3).to(dtype)
 
 
-def run(rank: int, world: int, port: int, queue) -> None:
+def run(rank: int, world: int, init_method: str, queue) -> None:
     try:
         import torch
         import torch.distributed as dist
         from oracle import all_reduce as oracle
         from splitwise_amd.model_executor.custom_all_reduce import CustomAllreduce
         torch.cuda.set_device(0)                  # every rank on the one GPU of the test box
-        dist.init_process_group("gloo", rank=rank, world_size=world, init_method=f"tcp://127.0.0.1:{port}")
+        dist.init_process_group("gloo", rank=rank, world_size=world, init_method=init_method)
         ar = CustomAllreduce(rank, world, max_size=8192 * 1024)
         bad = []
         for rounds in range(2):                   # twice: the counters of a second pass start where the first ended

@@ -1,5 +1,9 @@
-"""CPU stand-ins for the two workers of a split pair, used to drive the REAL control plane
-(engine -> SplitwiseExecutor -> channel -> worker_loop) across two processes without a GPU.
+"""CPU stand-ins for the workers of a split deployment, used to drive the REAL control plane
+(engine -> SplitwiseExecutor / PoolExecutor -> channel -> worker_loop) across processes without a GPU.
+With tensor-parallel pools (PoolExecutor) rank r of the prompt pool pushes to rank r + tp, every
+rank joins the real process groups over gloo, and every step all-reduces the sampled token over the
+pool's tensor-parallel group: ranks that disagree (a push that went to the wrong peer, a group that
+spans the wrong ranks) fail the step.
 
 The "KV cache" of a worker is a file-backed int64 array [num_blocks, block_size] holding token
 ids, plus an epoch flag per hand-off slot; the prompt side maps the token side's file (the
@@ -60,9 +64,16 @@ class _FakeRunner:
 
 class FakeWorker:
     def __init__(self, model_config, parallel_config, scheduler_config, device_config, local_rank, rank,
-                 kv_cache_dtype, is_driver_worker, kv_transport_init) -> None:
+                 kv_cache_dtype, is_driver_worker, kv_transport_init, distributed_init_method=None,
+                 distributed_store=None) -> None:
         self.rank = rank
-        self.is_prompt = rank == 0
+        self.parallel_config = parallel_config
+        self.tp = parallel_config.tensor_parallel_size
+        self.world = 2 * self.tp
+        self.peer = (rank + self.tp) % self.world
+        self.is_prompt = rank < self.tp
+        self.distributed_init_method = distributed_init_method
+        self.distributed_store = distributed_store
         self.exchange = kv_transport_init["exchange"]
         self.dir = os.environ["SPLIT_FAKE_DIR"]
         self.model_runner = _FakeRunner()
@@ -73,7 +84,36 @@ class FakeWorker:
 
     # ---- life cycle, as Worker
     def init_model(self) -> None:
-        pass
+        if self.tp == 1:
+            return
+        # the product's own group set-up (worker.py:66-100 of this package), on gloo
+        import datetime
+
+        import torch.distributed as dist
+
+        from splitwise_amd.model_executor import parallel_state
+        timeout = datetime.timedelta(seconds=120)
+        if self.distributed_store is not None:
+            dist.init_process_group("gloo", world_size=self.world, rank=self.rank, timeout=timeout,
+                                    store=dist.PrefixStore("default_pg", self.distributed_store))
+        else:
+            dist.init_process_group("gloo", world_size=self.world, rank=self.rank, timeout=timeout,
+                                    init_method=self.distributed_init_method)
+        parallel_state.initialize_model_parallel(self.tp, True)
+        assert parallel_state.get_tensor_model_parallel_rank() == self.rank % self.tp
+
+    def _agree(self, token: int) -> int:
+        """All ranks of the pool must have computed the same token: SUM over the tensor-parallel group."""
+        if self.tp == 1:
+            return token
+        import torch
+
+        from splitwise_amd.model_executor import parallel_state
+        total = parallel_state.tensor_model_parallel_all_reduce(torch.tensor([token, 1], dtype=torch.int64))
+        assert int(total[1]) == self.tp, f"the all-reduce spanned {int(total[1])} ranks, not {self.tp}"
+        if int(total[0]) != token * self.tp:
+            raise RuntimeError(f"rank {self.rank} sampled {token}, its pool's sum is {int(total[0])}")
+        return token
 
     def load_model(self) -> None:
         pass
@@ -99,11 +139,13 @@ class FakeWorker:
         pass
 
     def setup_kvcache_comm(self) -> None:
+        if os.environ.get("SPLIT_FAKE_DIE_IN_HANDSHAKE") == str(self.rank):
+            os._exit(3)                                    # a worker that dies before it has handed anything in
         peer = self.exchange({"rank": self.rank, "blocks": int(self.cache.shape[0])})
-        assert peer["rank"] == 1 - self.rank and peer["blocks"] == self.cache.shape[0], peer
+        assert peer["rank"] == self.peer and peer["blocks"] == self.cache.shape[0], peer
         if self.is_prompt:
-            self.peer_cache = np.load(os.path.join(self.dir, "cache1.npy"), mmap_mode="r+")
-            self.peer_flags = np.load(os.path.join(self.dir, "flags1.npy"), mmap_mode="r+")
+            self.peer_cache = np.load(os.path.join(self.dir, f"cache{self.peer}.npy"), mmap_mode="r+")
+            self.peer_flags = np.load(os.path.join(self.dir, f"flags{self.peer}.npy"), mmap_mode="r+")
         self.exchange({"rank": self.rank, "ready": True})
 
     def destroy_kvcache_comm(self) -> None:
@@ -135,7 +177,7 @@ class FakeWorker:
                 table = meta.block_tables[seq_id]
                 for pos, tok in enumerate(tokens):
                     self._write(table, pos, tok)
-                tok = next_token(tokens)
+                tok = self._agree(next_token(tokens))
                 outputs.append(SequenceGroupOutput([SequenceOutput(seq_id, tok, {tok: Logprob(0.0)})]))
             time.sleep(0.002)                              # the decode step on the other side overlaps this one
             for slot, runs in blocks_to_nw.items():
@@ -165,6 +207,6 @@ class FakeWorker:
             table = meta.block_tables[seq_id]
             self._write(table, n - 1, last)                          # this step's own KV entry
             cached = self._read(table, n)
-            tok = next_token(cached)
+            tok = self._agree(next_token(cached))
             outputs.append(SequenceGroupOutput([SequenceOutput(seq_id, tok, {tok: Logprob(0.0)})]))
         return SamplerOutput(outputs)

@@ -139,3 +139,40 @@ def test_http_generate_and_openai_routes():
         assert lines[-1] == "data: [DONE]" and len(lines) == 4
         assert json.loads(lines[2][6:])["choices"][0]["finish_reason"] == "length"
         assert client.post("/v1/chat/completions", json={"messages": [{"role": "user", "content": "hi"}]}).status_code == 400
+
+
+def test_engine_stats_use_one_clock():
+    """TTFT / TPOT / e2e / time in queue are differences against the request's monotonic arrival time:
+    they must come out as fractions of a second, not as the wall clock minus a monotonic reading."""
+    import conftest  # noqa: F401
+    from test_pipelined_engine_cpu import FakeExecutor
+    from splitwise_amd import EngineArgs, LLMEngine, SamplingParams
+    args = EngineArgs(model="llama-tiny", max_num_seqs=4, max_model_len=256, max_num_batched_tokens=256, swap_space=0.001)
+    mc, cc, pc, sc, dc = args.create_engine_configs()
+    cc.num_gpu_blocks, cc.num_cpu_blocks = 16, 8
+    engine = LLMEngine(mc, cc, pc, sc, dc, executor=FakeExecutor())
+    seen = []
+    engine._get_stats_orig = engine._get_stats
+
+    def spy(*a, **k):
+        stats = engine._get_stats_orig(*a, **k)
+        seen.append(stats)
+        return stats
+
+    engine._get_stats = spy
+
+    class _Log:
+        def log(self, stats):
+            pass
+
+    engine.stat_logger = _Log()
+    engine.add_request("r", None, SamplingParams(temperature=0.0, max_tokens=3, ignore_eos=True), prompt_token_ids=[1, 2, 3])
+    group = engine.scheduler.waiting[0]
+    while engine.has_unfinished_requests():
+        engine.step()
+    assert seen
+    for stats in seen:
+        for v in stats.time_to_first_tokens + stats.time_per_output_tokens + stats.time_e2e_requests:
+            assert 0.0 <= v < 5.0, v
+    assert 0.0 <= group.metrics.time_in_queue < 5.0
+    assert group.metrics.first_token_time > 1.0e9            # wall clock, as in the reference

@@ -130,6 +130,23 @@ def test_split_engine_generates_like_the_cpu_model(overlap):
         pushed = llm.llm_engine.model_executor.kv_bytes_pushed()
         blocks = sum(-(-len(p) // 16) for p in prompts)
         assert pushed == blocks * 2 * cfg["num_hidden_layers"] * 16 * 2 * 64 * 2      # K+V, bf16... f16 blocks
-        llm.llm_engine.model_executor.driver_worker.kvcache_comm_manager.check_status()
+        # the side that waits is the token worker: its status word is the one that can be set
+        llm.llm_engine.model_executor._remote_call("check_kv_status")
+    finally:
+        llm.llm_engine.model_executor.shutdown()
+
+
+def test_a_hand_off_signal_that_never_comes_fails_the_decode_step(monkeypatch):
+    """The prompt worker pushes the KV blocks but its signal is withheld: the token worker's bounded wait
+    runs out, and the engine must get a RuntimeError for that decode step instead of tokens computed on
+    blocks that were never announced (the reference's proxy_channel.wait(1e8) traps, kv_comm_kernels.cu:7)."""
+    from splitwise_amd import SamplingParams
+    monkeypatch.setenv("SPLITWISE_KV_WAIT_SPINS", "20000")          # the worker process inherits it
+    llm = _split_llm("kernel")
+    try:
+        comm = llm.llm_engine.model_executor.driver_worker.kvcache_comm_manager
+        monkeypatch.setattr(comm, "signal_and_flush", lambda *a, **k: None)
+        with pytest.raises(RuntimeError, match="hand-off wait timed out"):
+            llm.generate(prompt_token_ids=[[1, 2, 3, 4, 5]], sampling_params=SamplingParams(temperature=0.0, max_tokens=4))
     finally:
         llm.llm_engine.model_executor.shutdown()

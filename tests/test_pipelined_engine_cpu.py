@@ -141,3 +141,95 @@ def test_pipelined_late_arrivals_and_abort():
     assert out["r0"][:3] == plain["r0"][:3] and out["r2"][:3] == plain["r2"][:3]
     assert engine.scheduler.block_manager.get_num_free_gpu_blocks() == 64
     assert not engine.has_unfinished_requests()
+
+
+# ------------------------------------------------------------------ pipelined split pools
+class _PromptPending:
+    """A prompt step that stays 'running on the prompt GPU' until the test lets it finish."""
+
+    def __init__(self, metas):
+        self.metas = metas
+        self.finished = False
+
+    def done(self) -> bool:
+        return self.finished
+
+    def wait(self) -> None:
+        self.finished = True
+
+    def resolve(self) -> SamplerOutput:
+        return _sample(self.metas)
+
+
+class FakeSplitExecutor(ExecutorBase):
+    supports_pipelined_split = True
+
+    def __init__(self):
+        self.prompt_pending = None
+        self.decode_prev = None
+
+    def execute_split(self, prompt_kwargs, decode_kwargs):
+        raise AssertionError("the pipelined engine does not use the lock-stepped dispatch")
+
+    def execute_model(self, *a, **k):
+        raise AssertionError("unused")
+
+    def launch_prompt(self, kwargs):
+        self.prompt_pending = _PromptPending(kwargs["seq_group_metadata_list"])
+        return self.prompt_pending
+
+    def decode_deferred(self, kwargs):
+        prev, self.decode_prev = self.decode_prev, (kwargs["seq_group_metadata_list"] if kwargs else None)
+        return _sample(prev) if prev is not None else None
+
+    def check_health(self) -> None:
+        pass
+
+
+def test_abort_during_a_running_prompt_step_keeps_its_blocks_until_the_step_has_resolved():
+    """The prompt GPU writes and pushes KV into the token GPU's blocks on its own clock: blocks of a
+    sequence aborted while its prompt step runs must not be handed to another sequence before then."""
+    args = EngineArgs(model="llama-tiny", sep_prompt_token=True, max_num_seqs=4, max_model_len=256,
+                      max_num_batched_tokens=256, swap_space=0.001, pipeline_steps=True)
+    mc, cc, pc, sc, dc = args.create_engine_configs()
+    cc.num_gpu_blocks, cc.num_cpu_blocks = 8, 8
+    ex = FakeSplitExecutor()
+    engine = LLMEngine(mc, cc, pc, sc, dc, executor=ex)
+    assert engine.pipeline_split
+    bm = engine.scheduler.block_manager
+    params = SamplingParams(temperature=0.0, max_tokens=4, ignore_eos=True)
+    engine.add_request("a", None, params, prompt_token_ids=list(range(40)))       # 3 blocks
+    engine.step()                                                                  # its prompt step is launched
+    pending = ex.prompt_pending
+    assert pending is not None and not pending.done()
+    seq_a = engine.scheduler.running[0].get_seqs()[0]
+    blocks_a = set(bm.get_block_table(seq_a))
+    assert len(blocks_a) == 3 and bm.get_num_free_gpu_blocks() == 5
+    engine.abort_request("a")                                                      # e.g. the client went away
+    assert bm.get_num_free_gpu_blocks() == 5, "blocks of a running prompt step were freed by the abort"
+    # new work arrives and is scheduled while the aborted prompt still runs: it must get other blocks
+    engine.add_request("b", None, params, prompt_token_ids=list(range(100, 140)))
+    engine.step()
+    assert ex.prompt_pending is pending, "the prompt pool is still busy with the aborted step"
+    assert bm.get_num_free_gpu_blocks() == 5
+    pending.finished = True                                                        # the step ends on the GPU
+    outs = engine.step()                                                           # resolved, dropped; b is launched
+    assert all(o.request_id != "a" for o in outs)
+    assert ex.prompt_pending is not pending
+    seq_b = engine.scheduler.running[0].get_seqs()[0]
+    assert bm.get_num_free_gpu_blocks() == 8 - len(bm.get_block_table(seq_b))      # a's blocks came back
+    ex.prompt_pending.finished = True
+    final = {}
+    for _ in range(50):
+        for o in engine.step():
+            if o.finished:
+                final[o.request_id] = list(o.outputs[0].token_ids)
+        if ex.prompt_pending is not None:
+            ex.prompt_pending.finished = True
+        if not engine.has_unfinished_requests():
+            break
+    seq = list(range(100, 140))
+    for _ in range(4):
+        seq.append(next_token(seq))
+    assert final == {"b": seq[40:]}
+    assert bm.get_num_free_gpu_blocks() == 8

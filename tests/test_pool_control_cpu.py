@@ -1,0 +1,77 @@
+"""Tensor-parallel pools on CPU: PoolExecutor with tensor_parallel_size=4 and sep_prompt_token (a prompt
+pool of ranks 0-3 pushing to a token pool of ranks 4-7, the world of vllm/config.py:433-443) drives eight
+processes whose workers are CPU stand-ins (tests/split_fakes.py).  Product code under test: process
+spawning and the rendezvous store, the real tensor-parallel / stage groups over gloo
+(parallel_state.initialize_model_parallel), the per-rank KV-transport handshake (rank i <-> i + tp), the
+concurrent prompt-step / decode-step dispatch, sampled tokens reported by the first rank of a pool only,
+and the failure paths: a worker that dies must end the engine's wait with an error, never hang it."""
+import os
+import random
+import tempfile
+import time
+
+import pytest
+
+import conftest  # noqa: F401  (adds the package and the repo root to sys.path)
+
+
+def _engine(tp: int, tmp: str, blocks: int = 64):
+    from split_fakes import FakeWorker
+    from splitwise_amd import EngineArgs, LLMEngine
+    from splitwise_amd.executor.pool_executor import PoolExecutor
+    os.environ["SPLIT_FAKE_DIR"] = tmp
+    os.environ["SPLIT_FAKE_BLOCKS"] = str(blocks)
+    args = EngineArgs(model="llama-tiny", sep_prompt_token=True, tensor_parallel_size=tp, max_num_seqs=6,
+                      max_model_len=128, max_num_batched_tokens=512, swap_space=0.001)
+    mc, cc, pc, sc, dc = args.create_engine_configs()
+    assert pc.world_size == 2 * tp and pc.num_prompt_workers == tp
+    executor = PoolExecutor(mc, cc, pc, sc, dc, worker_cls=FakeWorker, devices=[0] * (2 * tp))
+    return LLMEngine(mc, cc, pc, sc, dc, executor=executor), executor, cc
+
+
+@pytest.mark.parametrize("tp", [2, 4])
+def test_split_pools_of_tensor_parallel_ranks(tp):
+    from split_fakes import VOCAB, next_token
+    from splitwise_amd import SamplingParams
+    with tempfile.TemporaryDirectory() as tmp:
+        engine, executor, cc = _engine(tp, tmp)
+        try:
+            assert cc.num_gpu_blocks == 64                      # the smallest over all ranks (token ranks offer 80)
+            assert executor.prompt_pool == list(range(tp)) and executor.token_pool == list(range(tp, 2 * tp))
+            rng = random.Random(1)
+            prompts = {str(i): [rng.randrange(VOCAB) for _ in range(rng.choice([1, 5, 16, 17, 40]))] for i in range(10)}
+            lens = {rid: rng.choice([1, 2, 9, 20]) for rid in prompts}
+            pending, finished, steps = list(prompts), {}, 0
+            while pending or engine.has_unfinished_requests():
+                if pending and steps % 2 == 0:
+                    rid = pending.pop(0)
+                    engine.add_request(rid, None, SamplingParams(temperature=0.0, max_tokens=lens[rid], ignore_eos=True),
+                                       prompt_token_ids=prompts[rid])
+                for out in engine.step():
+                    if out.finished:
+                        finished[out.request_id] = list(out.outputs[0].token_ids)
+                steps += 1
+                assert steps < 2000
+            for rid, prompt in prompts.items():
+                seq = list(prompt)
+                for _ in range(lens[rid]):
+                    seq.append(next_token(seq))
+                assert finished[rid] == seq[len(prompt):], rid
+            assert executor.kv_bytes_pushed() > 0
+        finally:
+            executor.shutdown()
+
+
+def test_a_worker_that_dies_in_the_handshake_fails_the_set_up_at_once(monkeypatch):
+    monkeypatch.setenv("SPLIT_FAKE_DIE_IN_HANDSHAKE", "3")          # a token-pool rank of the tp=2 world
+    monkeypatch.setenv("SPLITWISE_CONTROL_TIMEOUT_S", "60")
+    with tempfile.TemporaryDirectory() as tmp:
+        began = time.monotonic()
+        with pytest.raises(RuntimeError, match="worker 3"):
+            _engine(2, tmp)
+        assert time.monotonic() - began < 45                       # noticed through the dead process, not the deadline
+    import torch.distributed as dist
+    if dist.is_initialized():                                      # rank 0 lives in this process
+        from splitwise_amd.model_executor import parallel_state
+        parallel_state.destroy_model_parallel()
+        dist.destroy_process_group()

@@ -4,7 +4,6 @@ Everything else is the product code: scheduler split scheduling and hand-off epo
 overlapped dispatch, the object channel, the worker loop and the transport handshake."""
 import os
 import random
-import socket
 import tempfile
 
 import pytest
@@ -12,20 +11,14 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 
-def _free_port() -> int:
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        return s.getsockname()[1]
-
-
-def _rank_main(rank: int, port: int, tmpdir: str, result_path: str, blocks: int, pipeline: bool) -> None:
+def _rank_main(rank: int, init_method: str, tmpdir: str, result_path: str, blocks: int, pipeline: bool) -> None:
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     sys.path.insert(0, here)
     import conftest  # noqa: F401  (adds the package and the repo root to sys.path)
     os.environ["SPLIT_FAKE_DIR"] = tmpdir
     os.environ["SPLIT_FAKE_BLOCKS"] = str(blocks)
-    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=2)
+    dist.init_process_group("gloo", init_method=init_method, rank=rank, world_size=2)
     from split_fakes import VOCAB, FakeWorker, next_token
     from splitwise_amd import EngineArgs, LLMEngine, SamplingParams
     from splitwise_amd.executor.channel import DistChannel
@@ -96,7 +89,9 @@ def _rank_main(rank: int, port: int, tmpdir: str, result_path: str, blocks: int,
 def test_split_engine_over_gloo_world_size_2(blocks, pipeline):  # preempted, recomputed and handed over again
     with tempfile.TemporaryDirectory() as tmp:
         result = os.path.join(tmp, "result.txt")
-        mp.spawn(_rank_main, args=(_free_port(), tmp, result, blocks, pipeline), nprocs=2, join=True)
+        # rendezvous through a file: no port to pick before the ranks exist
+        mp.spawn(_rank_main, args=("file://" + os.path.join(tmp, "rendezvous"), tmp, result, blocks, pipeline),
+                 nprocs=2, join=True)
         assert open(result).read() == "ok"
 
 

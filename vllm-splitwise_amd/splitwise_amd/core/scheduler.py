@@ -17,7 +17,7 @@ deployment can keep a prompt step and a decode step in flight at the same time
 import enum
 import time
 from collections import defaultdict, deque
-from typing import Deque, Dict, Iterable, List, Optional, Set, Tuple, Union
+from typing import Callable, Deque, Dict, Iterable, List, Optional, Set, Tuple, Union
 
 from ..config import CacheConfig, SchedulerConfig
 from ..sequence import (Sequence, SequenceData, SequenceGroup, SequenceGroupMetadata, SequenceStatus)
@@ -90,6 +90,11 @@ class Scheduler:
         self.swapped: Deque[SequenceGroup] = deque()
         # split mode only: groups whose prompt step is still executing on the prompt pool
         self.prefilling: Set[str] = set()
+        # pipelined split pools: the engine names the sequences of steps that are still running on a
+        # pool; an abort must not hand their blocks (or hand-off slot) to anyone else before that
+        # step has resolved, because the prompt GPU writes and pushes KV on its own clock
+        self.in_flight: Callable[[Sequence], bool] = lambda seq: False
+        self.held_after_abort: List[Sequence] = []
 
     # -------------------------------------------------------------- queue admin
     def add_seq_group(self, seq_group: SequenceGroup) -> None:
@@ -106,7 +111,18 @@ class Scheduler:
                 for seq in group.get_seqs():
                     if not seq.is_finished():
                         seq.status = SequenceStatus.FINISHED_ABORTED
-                        self.free_seq(seq)
+                        if self.in_flight(seq):
+                            self.held_after_abort.append(seq)
+                        else:
+                            self.free_seq(seq)
+
+    def release_held(self) -> None:
+        """Frees the aborted sequences whose last step has resolved by now."""
+        still = [seq for seq in self.held_after_abort if self.in_flight(seq)]
+        for seq in self.held_after_abort:
+            if seq not in still:
+                self.free_seq(seq)
+        self.held_after_abort = still
 
     def has_unfinished_seqs(self) -> bool:
         return bool(self.waiting or self.running or self.swapped)
@@ -271,7 +287,7 @@ class Scheduler:
                                 blocks_to_copy, coalesce_blocks_by_id(blocks_to_nw), [])
 
     def _metadata(self, outputs: SchedulerOutputs, groups: Iterable[SequenceGroup]) -> List[SequenceGroupMetadata]:
-        now = time.time()
+        now = time.monotonic()        # the clock of arrival_time: time_in_queue is a difference of the two
         metas: List[SequenceGroupMetadata] = []
         for group in groups:
             group.maybe_set_first_scheduled_time(now)

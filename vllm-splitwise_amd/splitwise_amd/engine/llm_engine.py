@@ -61,6 +61,20 @@ class LLMEngine:
         self._prompt_inflight = None    # (pending samples, scheduler outputs, request ids)
         self._decode_inflight = None    # (scheduler outputs, [(group, sequence)])
         self._free_later: List[Sequence] = []
+        if self.pipeline_split:
+            self.scheduler.in_flight = self._seq_in_flight
+
+    def _seq_in_flight(self, seq: Sequence) -> bool:
+        """Pipelined split pools: is the sequence part of a prompt step or a decode step that has been
+        launched and not resolved yet?"""
+        if self._prompt_inflight is not None:
+            for group in self._prompt_inflight[1].scheduled_seq_groups:
+                if any(s.seq_id == seq.seq_id for s in group.get_seqs()):
+                    return True
+        if self._decode_inflight is not None:
+            if any(s.seq_id == seq.seq_id for _, s in self._decode_inflight[1]):
+                return True
+        return False
 
     @classmethod
     def from_engine_args(cls, engine_args: EngineArgs, **kwargs) -> "LLMEngine":
@@ -91,7 +105,8 @@ class LLMEngine:
 
     def has_unfinished_requests(self) -> bool:
         return (self.scheduler.has_unfinished_seqs() or self._inflight is not None
-                or self._prompt_inflight is not None or self._decode_inflight is not None or bool(self._free_later))
+                or self._prompt_inflight is not None or self._decode_inflight is not None or bool(self._free_later)
+                or bool(self.scheduler.held_after_abort))
 
     # --------------------------------------------------------------------- step
     def _check_stop(self, seq: Sequence, params: SamplingParams) -> None:
@@ -110,7 +125,8 @@ class LLMEngine:
 
     def _process_model_outputs(self, output: SamplerOutput, scheduler_outputs: SchedulerOutputs,
                                groups: Optional[List[SequenceGroup]] = None) -> List[RequestOutput]:
-        now = time.time()
+        now = time.monotonic()        # intervals (TTFT, TPOT, e2e) are taken against the monotonic arrival_time
+        wall = time.time()
         scheduled = list(scheduler_outputs.scheduled_seq_groups) if groups is None else groups
         for group, out in zip(scheduled, output):
             seq = group.get_seqs(status=SequenceStatus.RUNNING)[0]
@@ -121,7 +137,7 @@ class LLMEngine:
             self._check_stop(seq, group.sampling_params)
             if seq.is_finished():
                 self.scheduler.free_seq(seq)
-            group.maybe_set_first_token_time(now)
+            group.maybe_set_first_token_time(wall)
         self.scheduler.free_finished_seq_groups()
         request_outputs = [RequestOutput.from_seq_group(g) for g in scheduled]
         request_outputs += [RequestOutput.from_seq_group(g) for g in scheduler_outputs.ignored_seq_groups]
@@ -174,7 +190,8 @@ class LLMEngine:
         ``still_running``: ids of the sequences in a newer step that is already in flight (split
         pools only): their blocks must outlive that step, because the prompt GPU does not queue
         behind the token GPU's stream when it writes new KV into reused blocks."""
-        now = time.time()
+        now = time.monotonic()        # intervals (TTFT, TPOT, e2e) are taken against the monotonic arrival_time
+        wall = time.time()
         for seq in self._free_later:                     # their speculative extra step has resolved by now
             self.scheduler.free_seq(seq)
         self._free_later = []
@@ -202,7 +219,7 @@ class LLMEngine:
                         self.scheduler.free_seq(seq)
                     if group in self.scheduler.waiting:      # preempted for recomputation in the meantime
                         self.scheduler.waiting.remove(group)
-            group.maybe_set_first_token_time(now)
+            group.maybe_set_first_token_time(wall)
             reported.append(group)
         self.scheduler.free_finished_seq_groups()
         if self.stat_logger is not None:
@@ -278,6 +295,7 @@ class LLMEngine:
             progressed = True
         if not progressed and self._prompt_inflight is not None:
             self._prompt_inflight[0].wait()                    # nothing else to do: wait for the prompt step
+        self.scheduler.release_held()                          # aborted sequences whose last step has resolved
         return outputs
 
     def _step_pipelined(self) -> List[RequestOutput]:

@@ -13,8 +13,15 @@ class PipeChannel:
     def send(self, obj: Any) -> None:
         self.conn.send(obj)
 
-    def recv(self) -> Any:
+    def recv(self, timeout: float = None) -> Any:
+        """Blocks at most ``timeout`` seconds (None: for ever).  A peer that has gone away ends the wait at
+        once with EOFError (its end of the pipe closes with it); TimeoutError when nothing came in time."""
+        if timeout is not None and not self.conn.poll(timeout):
+            raise TimeoutError(f"no message on the control channel within {timeout:g} s")
         return self.conn.recv()
+
+    def poll(self, timeout: float = 0.0) -> bool:
+        return self.conn.poll(timeout)
 
     def close(self) -> None:
         self.conn.close()
@@ -31,11 +38,16 @@ class DistChannel:
         import torch.distributed as dist
         dist.send_object_list([obj], dst=self.peer, group=self.group)
 
-    def recv(self) -> Any:
+    def recv(self, timeout: float = None) -> Any:
+        """``timeout`` is the process group's own (set when it was created): a gloo receive cannot be
+        given another one per call."""
         import torch.distributed as dist
         box = [None]
         dist.recv_object_list(box, src=self.peer, group=self.group)
         return box[0]
+
+    def poll(self, timeout: float = 0.0) -> bool:
+        return True                    # no way to look without receiving: the receive itself then waits
 
     def close(self) -> None:
         pass

@@ -14,7 +14,8 @@ Differences from the reference, both deliberate:
     of a pool reports the sampled tokens;
   * with split pools, ``execute_split`` runs a prompt step and a decode step at the same time.
 """
-import socket
+import os
+import time
 from typing import Any, Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -27,10 +28,23 @@ from .executor_base import ExecutorBase
 from .gpu_executor import check_block_budget
 
 
-def _free_port() -> int:
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        return s.getsockname()[1]
+def _control_timeout() -> float:
+    """Longest wait for one reply of a worker process (seconds).  Generous: the first reply comes after
+    the model has been built and the memory profiled."""
+    return float(os.environ.get("SPLITWISE_CONTROL_TIMEOUT_S", "900"))
+
+
+def _listening_store(world_size: int):
+    """The rendezvous store of the workers' process group, served from THIS process on a port that
+    the kernel picks at bind time and that stays bound from then on.  (Looking for a free port first
+    and binding it later leaves a window in which any outgoing connection of any process can take the
+    number: rank 0 then fails to bind while the other ranks wait for a store that never comes up.)"""
+    import datetime
+
+    import torch.distributed as dist
+    store = dist.TCPStore("127.0.0.1", 0, world_size, is_master=True, wait_for_workers=False,
+                          timeout=datetime.timedelta(seconds=_control_timeout()))
+    return store, store.port
 
 
 class PoolExecutor(ExecutorBase):
@@ -43,6 +57,7 @@ class PoolExecutor(ExecutorBase):
         self.parallel_config = parallel_config
         self.scheduler_config = scheduler_config
         self.transport = transport
+        self.worker_cls = worker_cls
         self.tp = parallel_config.tensor_parallel_size
         self.split = parallel_config.sep_prompt_token
         self.world = parallel_config.world_size
@@ -53,7 +68,10 @@ class PoolExecutor(ExecutorBase):
             n = max(torch.cuda.device_count(), 1)
             devices = [r % n for r in range(self.world)]
         self.devices = list(devices)
-        init_method = f"tcp://127.0.0.1:{_free_port()}" if self.tp > 1 else None
+        init_method, store = None, None
+        if self.tp > 1:
+            store, port = _listening_store(self.world)
+            init_method = f"tcp://127.0.0.1:{port}"
         self.processes = []
         self.channels: Dict[int, Any] = dict(channels or {})
         if not self.channels and self.world > 1:
@@ -68,22 +86,29 @@ class PoolExecutor(ExecutorBase):
                 self.processes.append(proc)
                 self.channels[rank] = PipeChannel(parent)
         transport_init = {"exchange": self._exchange, "transport": transport} if self.split else None
-        extra = {"distributed_init_method": init_method} if init_method else {}
+        extra = {"distributed_init_method": init_method, "distributed_store": store} if init_method else {}
         self.driver_worker = worker_cls(model_config, parallel_config, scheduler_config, device_config,
                                         local_rank=self.devices[0], rank=0, kv_cache_dtype=cache_config.cache_dtype,
                                         is_driver_worker=True, kv_transport_init=transport_init, **extra)
         self.all_ranks = list(range(self.world))
         self.prompt_pool = list(range(self.tp))
         self.token_pool = list(range(self.tp, 2 * self.tp)) if self.split else self.prompt_pool
-        self._call_all(self.all_ranks, "init_model")
-        self._call_all(self.all_ranks, "load_model")
-        self._init_cache(num_gpu_blocks_override)
+        try:
+            self._call_all(self.all_ranks, "init_model")
+            self._call_all(self.all_ranks, "load_model")
+            self._init_cache(num_gpu_blocks_override)
+        except BaseException:
+            # the other ranks may be inside a collective or a rendezvous that will never complete now:
+            # do not talk to them, end them
+            self.shutdown(graceful=False)
+            raise
 
     def _remote_cfg(self, rank: int, init_method: Optional[str]) -> Dict[str, Any]:
         return {"model_config": self.model_config, "parallel_config": self.parallel_config,
                 "scheduler_config": self.scheduler_config, "cache_config": self.cache_config, "rank": rank,
                 "local_rank": self.devices[rank], "transport": self.transport,
-                "distributed_init_method": init_method, "reports_output": rank % self.tp == 0}
+                "distributed_init_method": init_method, "reports_output": rank % self.tp == 0,
+                "worker_cls": None if self.worker_cls is Worker else self.worker_cls}
 
     # ------------------------------------------------------------ control plane
     def _send(self, rank: int, name: str, kwargs: dict) -> None:
@@ -94,8 +119,27 @@ class PoolExecutor(ExecutorBase):
         else:
             self.channels[rank].send(("call", name, kwargs))
 
+    def _recv(self, rank: int, deadline: float):
+        """One message from ``rank``, looking once a second whether its process is still alive (a worker
+        that died inside a HIP call does not always get to close its end of the pipe at once)."""
+        ch = self.channels[rank]
+        proc = self.processes[rank - 1] if 0 < rank <= len(self.processes) else None
+        while True:
+            try:
+                return ch.recv(timeout=1.0)
+            except TimeoutError:
+                pass
+            except (EOFError, OSError) as exc:
+                raise RuntimeError(f"worker {rank} went away (exit code "
+                                   f"{proc.exitcode if proc is not None else 'unknown'})") from exc
+            if proc is not None and not proc.is_alive() and not ch.poll(0.0):
+                raise RuntimeError(f"worker {rank} died (exit code {proc.exitcode})")
+            if time.monotonic() > deadline:
+                raise RuntimeError(f"worker {rank} did not answer within {_control_timeout():g} s "
+                                   "(SPLITWISE_CONTROL_TIMEOUT_S)")
+
     def _wait(self, rank: int):
-        status, result = self.channels[rank].recv()
+        status, result = self._recv(rank, time.monotonic() + _control_timeout())
         if status == "samples":
             return unpack_sampler_output(result)
         if status != "ok":
@@ -108,8 +152,25 @@ class PoolExecutor(ExecutorBase):
         for r in remote:
             self._send(r, name, kwargs)
         results: Dict[int, Any] = {}
+        local_error = None
         if 0 in ranks:
-            results[0] = getattr(self.driver_worker, name)(**kwargs)
+            try:
+                results[0] = getattr(self.driver_worker, name)(**kwargs)
+            except Exception as exc:                # noqa: BLE001
+                local_error = exc
+        if local_error is not None:
+            # collect what the others have to say, briefly: their error is usually the cause of ours
+            remote_errors = []
+            for r in remote:
+                try:
+                    status, result = self._recv(r, time.monotonic() + 5.0)
+                    if status == "error":
+                        remote_errors.append(f"worker {r}: {result}")
+                except RuntimeError as exc:
+                    remote_errors.append(str(exc))
+            if remote_errors:
+                raise RuntimeError(f"{name} failed on rank 0 ({local_error}); " + "; ".join(remote_errors)) from local_error
+            raise local_error
         for r in remote:
             results[r] = self._wait(r)
         return results
@@ -117,16 +178,34 @@ class PoolExecutor(ExecutorBase):
     def _exchange(self, obj):
         """One round of the KV-transport handshake: every worker hands in one object and gets its
         pair's.  Runs inside the local prompt worker's set-up, which is when the others ask too."""
+        deadline = time.monotonic() + _control_timeout()
+        waiting = set(range(1, 2 * self.tp))
+        handed_in: Dict[int, Any] = {}
+        while waiting:                                      # in whatever order they arrive
+            progressed = False
+            for r in sorted(waiting):
+                if not self.channels[r].poll(0.0):
+                    continue
+                tag, payload = self._recv(r, deadline)
+                if tag == "error":                          # the worker's set-up failed before it got here
+                    raise RuntimeError(f"worker {r} failed during the KV-transport handshake: {payload}")
+                if tag != "kv_exchange":
+                    raise RuntimeError(f"worker {r} sent {tag!r} during the KV-transport handshake")
+                handed_in[r] = payload
+                waiting.discard(r)
+                progressed = True
+            if not progressed and waiting:
+                r = min(waiting)                            # block (bounded, liveness-checked) on one of them
+                tag, payload = self._recv(r, deadline)
+                if tag != "kv_exchange":
+                    raise RuntimeError(f"worker {r} failed during the KV-transport handshake: {tag!r} {payload}")
+                handed_in[r] = payload
+                waiting.discard(r)
         for i in range(1, self.tp):                         # pairs that live entirely in other processes
-            tag_a, a = self.channels[i].recv()
-            tag_b, b = self.channels[i + self.tp].recv()
-            assert tag_a == tag_b == "kv_exchange", (tag_a, tag_b)
-            self.channels[i].send(("kv_exchange", b))
-            self.channels[i + self.tp].send(("kv_exchange", a))
-        tag, peer = self.channels[self.tp].recv()           # the local worker's own pair
-        assert tag == "kv_exchange", tag
-        self.channels[self.tp].send(("kv_exchange", obj))
-        return peer
+            self.channels[i].send(("kv_exchange", handed_in[i + self.tp]))
+            self.channels[i + self.tp].send(("kv_exchange", handed_in[i]))
+        self.channels[self.tp].send(("kv_exchange", obj))   # the local worker's own pair
+        return handed_in[self.tp]
 
     # -------------------------------------------------------------------- cache
     def _init_cache(self, override: Optional[int]) -> None:
@@ -190,20 +269,31 @@ class PoolExecutor(ExecutorBase):
             if not proc.is_alive():
                 raise RuntimeError("a worker process died")
 
-    def shutdown(self) -> None:
+    def shutdown(self, graceful: bool = True) -> None:
+        """Ends the worker processes.  Never waits on a worker for long: one that is stuck (inside a
+        rendezvous, a collective or a HIP call) is killed."""
         try:
             if self.split:
                 self.driver_worker.destroy_kvcache_comm()
-            for ch in self.channels.values():
-                ch.send(("shutdown",))
-            for ch in self.channels.values():
-                ch.recv()
         except Exception:
             pass
+        if graceful:
+            for ch in self.channels.values():
+                try:
+                    ch.send(("shutdown",))
+                except Exception:
+                    pass
+            deadline = time.monotonic() + 10.0
+            for ch in self.channels.values():
+                try:
+                    ch.recv(timeout=max(deadline - time.monotonic(), 0.1))
+                except Exception:
+                    pass
         for proc in self.processes:
-            proc.join(timeout=10)
+            proc.join(timeout=10 if graceful else 0.1)
             if proc.is_alive():
                 proc.kill()
+                proc.join(timeout=5)
         self.processes = []
         self.channels = {}
         if self.tp > 1:

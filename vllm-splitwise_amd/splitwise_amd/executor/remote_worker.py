@@ -92,5 +92,7 @@ def spawn_entry(conn, cfg: Dict[str, Any]) -> None:
         import faulthandler
         import sys
         faulthandler.dump_traceback_later(float(os.environ["SPLITWISE_DEBUG_HANG"]), repeat=False, file=sys.stderr)
-    torch.cuda.set_device(cfg["local_rank"])
-    worker_loop(PipeChannel(conn), cfg)
+    worker_cls = cfg.get("worker_cls") or Worker      # tests drive the control plane with CPU stand-ins
+    if worker_cls is Worker:
+        torch.cuda.set_device(cfg["local_rank"])
+    worker_loop(PipeChannel(conn), cfg, worker_cls=worker_cls)

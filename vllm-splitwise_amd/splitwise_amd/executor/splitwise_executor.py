@@ -72,19 +72,30 @@ class SplitwiseExecutor(ExecutorBase):
     # ------------------------------------------------------------ control plane
     def _exchange(self, obj):
         """KV-transport handshake of the local prompt worker with the remote token worker."""
-        tag, peer = self._recv_skipping_nothing()
-        assert tag == "kv_exchange", tag
+        tag, peer = self._recv()
+        if tag != "kv_exchange":          # e.g. ("error", traceback): the worker's set-up failed before it got here
+            raise RuntimeError(f"token worker failed during the KV-transport handshake: {tag!r} {peer}")
         self.channel.send(("kv_exchange", obj))
         return peer
-
-    def _recv_skipping_nothing(self):
-        return self.channel.recv()
 
     def _remote_async(self, name: str, **kwargs) -> None:
         self.channel.send(("call", name, kwargs))
 
+    def _recv(self):
+        """The token worker's next message; a worker that has died ends the wait with an error."""
+        if self.process is None or not hasattr(self.channel, "poll"):
+            return self.channel.recv()
+        while True:
+            try:
+                return self.channel.recv(timeout=1.0)
+            except TimeoutError:
+                if not self.process.is_alive() and not self.channel.poll(0.0):
+                    raise RuntimeError(f"token worker process died (exit code {self.process.exitcode})") from None
+            except (EOFError, OSError) as exc:
+                raise RuntimeError(f"token worker process went away (exit code {self.process.exitcode})") from exc
+
     def _remote_wait(self):
-        status, result = self.channel.recv()
+        status, result = self._recv()
         if status == "samples":
             return unpack_sampler_output(result)
         if status != "ok":
@@ -180,7 +191,7 @@ class SplitwiseExecutor(ExecutorBase):
         try:
             self.driver_worker.destroy_kvcache_comm()
             self.channel.send(("shutdown",))
-            self.channel.recv()
+            self.channel.recv(timeout=10.0)          # a stuck worker is killed below, not waited for
         except Exception:
             pass
         if self.process is not None:

@@ -37,10 +37,22 @@ class CustomAllreduce:
         self.scratch_off = _align(_C.custom_ar.signal_bytes(), 256)
         self.staging_off = self.scratch_off + _align(max_size, 256)
         total = self.staging_off + _align(max_size, 256)
-        self.buffer = torch.zeros(total, dtype=torch.uint8, device=self.device)        # zeroed signal area
+        from ..worker.kv_comm import _IPC_OPEN_TIMEOUT_S, _bounded, _ipc_safe_size
+        # A device allocation of its own, never a piece of a segment that the caching allocator has kept
+        # from earlier tensors: a handle names the whole allocation, and a peer's hipIpcOpenMemHandle
+        # never returns for allocations of some sizes (see _ipc_safe_size)
+        if self.device.type == "cuda":
+            self._pool = torch.cuda.MemPool()
+            with torch.cuda.use_mem_pool(self._pool, device=self.device):
+                self.buffer = torch.zeros(total, dtype=torch.uint8, device=self.device)    # zeroed signal area
+        else:
+            self.buffer = torch.zeros(total, dtype=torch.uint8, device=self.device)
         torch.cuda.synchronize(self.device)
-        # a handle names a whole device allocation; the buffer's offset inside it travels beside it
-        alloc_base, _ = _C.kv_ops.mem_address_range(self.buffer.data_ptr())
+        # the buffer's offset inside its allocation travels beside the handle
+        alloc_base, alloc_bytes = _C.kv_ops.mem_address_range(self.buffer.data_ptr())
+        if _ipc_safe_size(alloc_bytes) != alloc_bytes:
+            raise RuntimeError(f"the all-reduce buffer lives in a device allocation of {alloc_bytes} bytes, "
+                               "which a peer process cannot map on this runtime")
         mine = (_C.kv_ops.ipc_get_mem_handle(alloc_base), self.buffer.data_ptr() - alloc_base)
         everyone: List = [None] * world_size
         dist.all_gather_object(everyone, mine, group=group)
@@ -50,7 +62,8 @@ class CustomAllreduce:
             if r == rank:
                 bases.append(self.buffer.data_ptr())
             else:
-                mapped = _C.kv_ops.ipc_open_mem_handle(handle)
+                mapped = _bounded(lambda h=handle: _C.kv_ops.ipc_open_mem_handle(h), _IPC_OPEN_TIMEOUT_S,
+                                  f"mapping rank {r}'s all-reduce buffer (hipIpcOpenMemHandle)")
                 self._mappings.append(mapped)
                 bases.append(mapped + offset)
         self._ptr = _C.custom_ar.init(bases, rank, self.signal_off, self.scratch_off, self.staging_off, max_size)

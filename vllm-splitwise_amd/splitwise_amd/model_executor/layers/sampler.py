@@ -66,6 +66,7 @@ class PendingSamples:
             for seq_id in seq_ids:
                 self.row_of[seq_id] = len(self.row_of)
         self.event = None
+        self.after_sync = []         # callables run by resolve() once the step has finished on the device
         if next_ids.is_cuda:
             self._ids = torch.empty(next_ids.shape, dtype=next_ids.dtype, pin_memory=True)
             self._ids.copy_(next_ids, non_blocking=True)
@@ -89,6 +90,9 @@ class PendingSamples:
     def resolve(self) -> SamplerOutput:
         if self.event is not None:
             self.event.synchronize()
+        checks, self.after_sync = self.after_sync, []
+        for check in checks:         # e.g. the worker's look at its hand-off / all-reduce status words
+            check()
         return _build_output(self.seq_groups, self._ids.tolist(), None if self._lp is None else self._lp.tolist())
 
 
@@ -141,9 +145,11 @@ class Sampler(nn.Module):
         all_greedy = all(p.sampling_type == SamplingType.GREEDY for p in rows)
         want_logprobs = any(p.logprobs is not None for p in rows)
         if all_greedy and not want_logprobs:
-            # fast path: argmax of the logits equals argmax of the log-probs
-            next_ids = torch.argmax(logits, dim=-1)
-            chosen_lp = None
+            # fast path: argmax of the logits equals argmax of the log-probs; the sampled token's
+            # log-probability is its logit minus the row's log-sum-exp (sampler.py:417 of the reference
+            # takes it from the full log-softmax)
+            top, next_ids = torch.max(logits, dim=-1)
+            chosen_lp = top - torch.logsumexp(logits, dim=-1)
         else:
             temps = [p.temperature if p.temperature >= _EPS else 1.0 for p in rows]
             if any(t != 1.0 for t in temps):

@@ -38,6 +38,8 @@ class CacheEngine:
         self.dtype = _cache_torch_dtype(cache_config.cache_dtype, model_config.dtype)
         self.device = device
         self.gpu_slab: Optional[torch.Tensor] = None
+        # only a worker of a prompt/token pair exports its slab to another process
+        self.exported_to_peer = bool(getattr(parallel_config, "sep_prompt_token", False))
         self.gpu_cache = self._allocate_gpu_slab(self.num_gpu_blocks, device)
         self.cpu_cache = self._allocate(self.num_cpu_blocks, torch.device("cpu"), pinned=device.type == "cuda")
         self.cache_stream = torch.cuda.Stream(device) if device.type == "cuda" else None
@@ -58,7 +60,8 @@ class CacheEngine:
         es = torch.tensor([], dtype=self.dtype).element_size()
         kshape, vshape = self.get_key_block_shape(), self.get_value_block_shape()
         block_elems = self.num_heads * self.head_size * self.block_size
-        offsets, _, total = slab_layout(self.num_layers, block_elems * es, num_blocks)
+        offsets, _, total = slab_layout(self.num_layers, block_elems * es, num_blocks,
+                                        pad_for_ipc=self.exported_to_peer)
         # A device allocation of its own, never a piece of a segment the caching allocator has kept
         # from earlier tensors: the paired worker maps the allocation the slab lives in, and only
         # the size slab_layout() chose is known to be mappable.

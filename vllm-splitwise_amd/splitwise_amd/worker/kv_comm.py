@@ -29,7 +29,7 @@ FLAG_BYTES = 4096                 # MAX_SLOT_IDS int32 flags + a status word, pa
 _MAX_SPINS = 5_000_000            # bounded wait, about 10 s
 
 
-_IPC_OPEN_TIMEOUT_S = 120.0
+_IPC_OPEN_TIMEOUT_S = 60.0
 
 
 class TransportSetupTimeout(RuntimeError):
@@ -81,9 +81,12 @@ def _ipc_safe_size(nbytes: int) -> int:
     return nbytes
 
 
-def slab_layout(num_layers: int, key_block_bytes: int, num_blocks: int) -> Tuple[List[Tuple[int, int]], int, int]:
+def slab_layout(num_layers: int, key_block_bytes: int, num_blocks: int,
+                pad_for_ipc: bool = True) -> Tuple[List[Tuple[int, int]], int, int]:
     """Byte offsets of every layer's (K, V) tensor inside one cache slab, the offset of the
-    flag area and the slab size.  Both workers of a pair compute the same layout."""
+    flag area and the slab size.  Both workers of a pair compute the same layout.  ``pad_for_ipc``
+    (workers with a peer) moves the size out of the band a peer process cannot map; a co-located
+    engine has nobody to export the slab to and takes exactly what the block budget allows."""
     offsets = []
     cursor = 0
     per_tensor = key_block_bytes * num_blocks
@@ -93,7 +96,9 @@ def slab_layout(num_layers: int, key_block_bytes: int, num_blocks: int) -> Tuple
         v_off = cursor + per_tensor_aligned
         offsets.append((k_off, v_off))
         cursor += 2 * per_tensor_aligned
-    total = _ipc_safe_size(cursor + FLAG_BYTES)
+    total = cursor + FLAG_BYTES
+    if pad_for_ipc:
+        total = _ipc_safe_size(total)
     return offsets, total - FLAG_BYTES, total
 
 
@@ -112,6 +117,13 @@ class KVCacheCommunicator:
         self.signal_epoch = [0] * MAX_SLOT_IDS
         self.wait_epoch = [0] * MAX_SLOT_IDS
         self.bytes_pushed = 0
+        # where a wait that ran out of its spin bound leaves 1 + slot: a word of pinned host memory that the
+        # wait kernel stores to directly, so the worker can look at it after every step's own
+        # synchronisation (the copy of the sampled tokens) without another device round trip
+        self.status_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        import os
+        # polls before a wait gives up (read once, at set-up; tests shorten it)
+        self.max_spins = int(os.environ.get("SPLITWISE_KV_WAIT_SPINS", _MAX_SPINS))
         # runtime transport state
         self.local_bytes: Optional[torch.Tensor] = None
         self.peer_bytes: Optional[torch.Tensor] = None
@@ -156,8 +168,16 @@ class KVCacheCommunicator:
             epoch = self.wait_epoch[sem_id] + 1
         self.wait_epoch[sem_id] = epoch
         flags = self.local_base + self.flags_offset
-        status = flags + 4 * MAX_SLOT_IDS
-        _C.kv_ops.kv_wait(flags, sem_id, epoch, _MAX_SPINS, status, self._stream())
+        _C.kv_ops.kv_wait(flags, sem_id, epoch, self.max_spins, self.status_host.data_ptr(), self._stream())
+
+    def check_status(self) -> None:
+        """Raises if a wait of a step that has FINISHED on the device ran out of its spin bound (reads host
+        memory only: call it after the step's own synchronisation)."""
+        status = int(self.status_host[0])
+        if status != 0:
+            self.status_host[0] = 0
+            raise RuntimeError(f"KV hand-off wait timed out on slot {status - 1}: the prompt worker's signal "
+                               "never arrived, the decode step ran on KV blocks that were not delivered")
 
 
 class KVCacheCommManager:
@@ -240,10 +260,14 @@ class KVCacheCommManager:
         comm = self.kvcache_comm
         if comm is None or self._slab is None:
             return
-        off = comm.flags_offset + 4 * MAX_SLOT_IDS
-        status = int(self._slab[off:off + 4].view(torch.int32).item())
-        if status != 0:
-            raise RuntimeError(f"KV hand-off wait timed out on slot {status - 1}")
+        torch.cuda.synchronize(comm.device)
+        comm.check_status()
+
+    def check_status_after_step(self) -> None:
+        """The same check without a synchronisation of its own, for the end of a step whose samples
+        have already reached the host."""
+        if self.kvcache_comm is not None:
+            self.kvcache_comm.check_status()
 
     def wait(self, sem_id: int, epoch: Optional[int] = None) -> None:
         self.kvcache_comm.wait(sem_id, epoch)

@@ -33,7 +33,9 @@ class Worker:
     def __init__(self, model_config: ModelConfig, parallel_config: ParallelConfig,
                  scheduler_config: SchedulerConfig, device_config: DeviceConfig, local_rank: int = 0,
                  rank: int = 0, distributed_init_method: Optional[str] = None, kv_cache_dtype: str = "auto",
-                 is_driver_worker: bool = True, kv_transport_init: Optional[dict] = None) -> None:
+                 is_driver_worker: bool = True, kv_transport_init: Optional[dict] = None,
+                 distributed_store=None) -> None:
+        self.distributed_store = distributed_store    # rank 0 of a pool executor: the store it already serves
         self.model_config = model_config
         self.parallel_config = parallel_config
         self.scheduler_config = scheduler_config
@@ -81,9 +83,15 @@ class Worker:
             import datetime
             # bounded: a rank that died while starting must not leave the others waiting for half an hour
             timeout = datetime.timedelta(seconds=float(os.environ.get("SPLITWISE_DIST_TIMEOUT_S", "600")))
-            dist.init_process_group(backend=os.environ.get("SPLITWISE_TP_BACKEND", "nccl"),
-                                    world_size=self.parallel_config.world_size, rank=self.rank,
-                                    init_method=self.distributed_init_method, timeout=timeout)
+            backend = os.environ.get("SPLITWISE_TP_BACKEND", "nccl")
+            if self.distributed_store is not None:
+                # the store is up already (its port was bound when it was picked); the key prefix is the
+                # one init_process_group puts in front of a store it builds from an init_method itself
+                dist.init_process_group(backend=backend, world_size=self.parallel_config.world_size, rank=self.rank,
+                                        store=dist.PrefixStore("default_pg", self.distributed_store), timeout=timeout)
+            else:
+                dist.init_process_group(backend=backend, world_size=self.parallel_config.world_size, rank=self.rank,
+                                        init_method=self.distributed_init_method, timeout=timeout)
         if dist.is_initialized() and self.parallel_config.tensor_parallel_size > 1:
             warm = torch.zeros(1, device="cpu" if dist.get_backend() == "gloo" else self.device)
             dist.all_reduce(warm)                                      # warm-up (worker.py:452-455)
@@ -209,7 +217,30 @@ class Worker:
         if blocks_to_nw and comm is not None and self.is_prompt_worker() and is_prompt:
             for sem_id in blocks_to_nw:
                 comm.signal_and_flush(sem_id, nw_epochs.get(sem_id))
+        # a bounded wait that gave up (hand-off signal, all-reduce barrier) lets the stream run on over
+        # data that never arrived: look at the status words once the step has finished and fail loudly
+        # (the reference's proxy_channel.wait(1e8) traps, its all-reduce barrier hangs)
+        if defer and hasattr(output, "after_sync"):
+            output.after_sync.append(self.check_step_status)
+        else:
+            self.check_step_status()
         return output
+
+    def check_step_status(self) -> None:
+        """Raises RuntimeError when a device-side wait of a FINISHED step timed out."""
+        comm = self.kvcache_comm_manager
+        if comm is not None and self.is_token_worker():
+            comm.check_status_after_step()
+        if self.parallel_config.tensor_parallel_size > 1:
+            from ..model_executor.custom_all_reduce import get_handle
+            handle = get_handle()
+            if handle is not None:
+                handle.check_status()
+
+    def check_kv_status(self) -> None:
+        """Host-synchronising form for callers outside a step (tests, the end of a benchmark)."""
+        if self.kvcache_comm_manager is not None:
+            self.kvcache_comm_manager.check_status()
 
     # ------------------------------------------- transport self-test (worker.py:350-386)
     def set_gpucache(self) -> None:
