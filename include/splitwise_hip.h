@@ -45,8 +45,9 @@ typedef enum sw_dtype {
 const char* sw_last_error(void);
 /* Version of this interface; sw_abi_version() returns the one the library was built from.
  * 2: sw_awq_to_kmajor, sw_int4_kmajor_gemm, sw_int4_kmajor_dequant added.
- * 3: sw_paged_attention_v2_static, sw_paged_attention_v2_static_max_bytes added. */
-#define SW_ABI_VERSION 3
+ * 3: sw_paged_attention_v2_static, sw_paged_attention_v2_static_max_bytes added.
+ * 4: sw_kv_push takes max_workgroups. */
+#define SW_ABI_VERSION 4
 int sw_abi_version(void);
 
 /* csrc/cuda_utils_kernels.cu:16-35 get_max_shared_memory_per_block_device_attribute:
@@ -191,9 +192,12 @@ int sw_ipc_close_mem_handle(void* dev_ptr);
 /* nw_cache_out_kernel / KVCacheCommunicator.put (comm_utils.py:132-147): copy num_runs byte
  * ranges src_base + offsets[i] -> dst_base + offsets[i] (same offset on both sides), each
  * nbytes[i] long; offsets and sizes are HOST arrays and multiples of 16.  dst_base is normally
- * the IPC mapping of the peer worker's cache.  Stream-ordered, non-blocking on the host.  */
+ * the IPC mapping of the peer worker's cache.  Stream-ordered, non-blocking on the host.
+ * max_workgroups > 0 caps the launch (each workgroup then walks several 64 KiB chunks): a push
+ * over one xGMI link needs few workgroups to fill the link and should leave the compute units to
+ * the kernels it runs beside; <= 0 launches one workgroup per chunk (device-local copies).     */
 int sw_kv_push(void* dst_base, const void* src_base, const int64_t* offsets,
-               const int64_t* nbytes, int num_runs, void* stream);
+               const int64_t* nbytes, int num_runs, int max_workgroups, void* stream);
 
 /* nw_cache_out_signal_kernel (kv_comm_kernels.cu:22-29): after a system-scope release,
  * flags[slot] := epoch in the PEER's flag array (IPC mapping).  Ordered after every earlier

@@ -33,3 +33,56 @@ def test_all_reduce_matches_reference_order_bit_for_bit(world):
                     p.kill()
     for rank, bad in sorted(results):
         assert bad == [], f"rank {rank}: {bad}"
+
+
+def _rccl_single_rank(init_method: str, queue) -> None:
+    """As much of the default ("nccl" = RCCL) collective path as one GPU allows: backend start-up, the
+    tensor-parallel group helpers, a message above the peer-read kernel's 8 MiB limit (the size class that
+    always goes to RCCL), all-gather and broadcast on a sub-group.  RCCL refuses two ranks on one
+    device, so the group has one member; what this guards is that the first multi-GPU run is not also
+    the first time this code and the library's communicator set-up execute."""
+    try:
+        import os
+        import sys
+        here = os.path.dirname(os.path.abspath(__file__))
+        sys.path.insert(0, here)
+        import conftest  # noqa: F401
+        import torch
+        import torch.distributed as dist
+        from splitwise_amd.model_executor import parallel_state
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1, init_method=init_method)
+        assert dist.get_backend() == "nccl"
+        group = dist.new_group([0])
+        big = torch.full((9 * 1024 * 1024 // 2,), 1.5, dtype=torch.bfloat16, device="cuda")      # 9 MiB
+        dist.all_reduce(big, group=group)
+        parts = [torch.empty(8, device="cuda")]
+        dist.all_gather(parts, torch.arange(8, dtype=torch.float32, device="cuda"), group=group)
+        dist.broadcast(big, src=0, group=group)
+        torch.cuda.synchronize()
+        ok = bool((big == 1.5).all()) and parts[0].tolist() == list(range(8))
+        # the package's own entry points with a group of one are pass-throughs
+        parallel_state.initialize_model_parallel(1)
+        x = torch.ones(4, device="cuda")
+        ok = ok and parallel_state.tensor_model_parallel_all_reduce(x) is x
+        ok = ok and parallel_state.tensor_model_parallel_all_gather(x) is x
+        dist.destroy_process_group()
+        queue.put("ok" if ok else "wrong values")
+    except BaseException:                         # noqa: BLE001
+        import traceback
+        queue.put(traceback.format_exc())
+
+
+def test_rccl_backend_starts_and_reduces_on_one_gpu():
+    ctx = mp.get_context("spawn")
+    queue = ctx.Queue()
+    with tempfile.TemporaryDirectory() as tmp:
+        proc = ctx.Process(target=_rccl_single_rank, args=("file://" + os.path.join(tmp, "rendezvous"), queue), daemon=True)
+        proc.start()
+        try:
+            verdict = queue.get(timeout=100)
+        finally:
+            proc.join(timeout=10)
+            if proc.is_alive():
+                proc.kill()
+    assert verdict == "ok", verdict

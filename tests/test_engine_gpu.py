@@ -105,21 +105,28 @@ def test_padded_and_packed_prompt_layouts_agree():
     torch.cuda.empty_cache()
 
 
-@pytest.mark.parametrize("split", [False, True])
-def test_tensor_parallel_pools_match_cpu_model(split, monkeypatch):
-    """Two tensor-parallel ranks per pool (co-located, then a prompt pool pushing its KV shards to a
-    token pool: four worker processes), all on this one GPU with gloo standing in for RCCL.  The
-    sharded model is the same seeded model as the unsharded one, so the whole-model CPU oracle on
-    the full weights judges the tokens."""
+@pytest.mark.parametrize("tp,split,eager", [(2, False, True), (2, False, False), (2, True, False), (4, True, False),
+                                            (4, True, True)])
+def test_tensor_parallel_pools_match_cpu_model(tp, split, eager, monkeypatch):
+    """Tensor-parallel ranks per pool (co-located, then a prompt pool pushing its KV shards to a token
+    pool: up to eight worker processes -- two pools of four, the 70B configuration in miniature, with
+    the two KV heads replicated over the four ranks), all on this one GPU with gloo standing in for
+    RCCL.  Without ``eager`` the decode steps are replayed HIP graphs that hold the layers'
+    all-reduces.  The sharded model is the same seeded model as the unsharded one, so the whole-model
+    CPU oracle on the full weights judges the tokens."""
     from splitwise_amd import LLM, SamplingParams
     from splitwise_amd.config import ModelConfig
     from splitwise_amd.model_executor.model_loader import get_model
     monkeypatch.setenv("SPLITWISE_TP_BACKEND", "gloo")
     random.seed(3)
-    llm = LLM("llama-tiny", tensor_parallel_size=2, sep_prompt_token=split, num_gpu_blocks_override=128,
-              max_num_seqs=8, max_model_len=512, swap_space=0.01)
+    llm = LLM("llama-tiny", tensor_parallel_size=tp, sep_prompt_token=split, num_gpu_blocks_override=128,
+              max_num_seqs=8, max_model_len=512, swap_space=0.01, enforce_eager=eager)
     from splitwise_amd.model_executor import custom_all_reduce
     assert custom_all_reduce.is_initialized()          # the pools' all-reduces run as direct peer reads
+    ex = llm.llm_engine.model_executor
+    decode_rank = tp if split else 0
+    graphs = ex._call_all([decode_rank], "num_captured_graphs")[decode_rank]
+    assert (graphs == 0) == eager, graphs
     try:
         vocab = llm.llm_engine.model_config.get_vocab_size()
         prompts = [[random.randrange(vocab) for _ in range(n)] for n in (5, 33, 64, 17, 100, 1, 48)]

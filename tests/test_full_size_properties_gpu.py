@@ -16,16 +16,16 @@ pytestmark = pytest.mark.gpu
 H, D, BS = 32, 128, 16
 
 
-def _decode_case(num_seqs=256, lo=800, hi=943, dtype=torch.bfloat16, seed=0):
+def _decode_case(num_seqs=256, lo=800, hi=943, dtype=torch.bfloat16, seed=0, heads=H, kv_heads=H):
     g = torch.Generator(device="cuda").manual_seed(seed)
     random.seed(seed)
     ctx = [random.randint(lo, hi) for _ in range(num_seqs)]
     per_seq = -(-hi // BS)
     num_blocks = num_seqs * per_seq
     scale = D ** -0.5
-    q = (torch.rand(num_seqs, H, D, device="cuda", generator=g) * 2 - 1).mul_(scale).to(dtype)
-    kc = (torch.rand(num_blocks, H, D // 8, BS, 8, device="cuda", generator=g) * 2 - 1).mul_(scale).to(dtype)
-    vc = (torch.rand(num_blocks, H, D, BS, device="cuda", generator=g) * 2 - 1).mul_(scale).to(dtype)
+    q = (torch.rand(num_seqs, heads, D, device="cuda", generator=g) * 2 - 1).mul_(scale).to(dtype)
+    kc = (torch.rand(num_blocks, kv_heads, D // 8, BS, 8, device="cuda", generator=g) * 2 - 1).mul_(scale).to(dtype)
+    vc = (torch.rand(num_blocks, kv_heads, D, BS, device="cuda", generator=g) * 2 - 1).mul_(scale).to(dtype)
     tables = torch.randperm(num_blocks, device="cuda", generator=g).to(torch.int32).view(num_seqs, per_seq)
     lens = torch.tensor(ctx, dtype=torch.int32, device="cuda")
     return q, kc, vc, tables, lens, scale
@@ -50,6 +50,55 @@ def test_decode_attention_properties_at_bench_size():
     const = torch.full_like(vc, 0.5)
     out = run_kernel("v1", q, kc, const, *args)
     torch.testing.assert_close(out.float(), torch.full_like(out, 0.5).float(), atol=4e-3, rtol=0)
+
+
+@pytest.mark.parametrize("num_seqs,hi", [(64, 4096), (256, 2048)])
+@pytest.mark.parametrize("kv_cache", ["auto", "fp8_e5m2"])
+def test_decode_attention_properties_at_the_70b_tp4_shape(num_seqs, hi, kv_cache):
+    """One rank of Llama-2-70B under tensor parallelism 4: 16 query heads over 2 KV heads (8 query heads
+    share every K / V byte), bf16, 64-256 sequences of 2-4 K tokens.  Size-independent properties, and
+    one sequence of the batch against the CPU oracle at the reference's tolerance."""
+    from helpers import make_kv_caches  # noqa: F401  (same distribution as the small fixtures)
+    from oracle import attention as oattn
+    heads, kv_heads = 16, 2
+    q, kc, vc, tables, lens, scale = _decode_case(num_seqs, hi // 2, hi, heads=heads, kv_heads=kv_heads, seed=5)
+    if kv_cache == "fp8_e5m2":
+        from splitwise_amd import _C
+        kc8, vc8 = torch.empty_like(kc, dtype=torch.uint8), torch.empty_like(vc, dtype=torch.uint8)
+        _C.cache_ops.convert_fp8_e5m2(kc.contiguous(), kc8)
+        _C.cache_ops.convert_fp8_e5m2(vc.contiguous(), vc8)
+        kc, vc = kc8, vc8
+    args = (kv_heads, scale, tables, lens, BS, None, kv_cache)
+    v1 = run_kernel("v1", q, kc, vc, *args)
+    v2 = run_kernel("v2", q, kc, vc, *args)
+    assert torch.isfinite(v1.float()).all()
+    torch.testing.assert_close(v1.float(), v2.float(), atol=1e-3, rtol=1e-2)
+    # each query head alone (as its own one-head launch over its KV head) gives the grouped launch's row
+    for head in (0, 7, 8, 15):
+        kv = head // (heads // kv_heads)
+        alone = run_kernel("v1", q[:, head:head + 1].contiguous(), kc[:, kv:kv + 1].contiguous(),
+                           vc[:, kv:kv + 1].contiguous(), 1, scale, tables, lens, BS, None, kv_cache)
+        torch.testing.assert_close(alone[:, 0].float(), v1[:, head].float(), atol=2e-3 if kv_cache == "auto" else 1e-2,
+                                   rtol=1e-2)
+    # the physical placement of the blocks is invisible
+    perm = torch.randperm(kc.shape[0], device="cuda")
+    inv = torch.empty_like(perm)
+    inv[perm] = torch.arange(perm.numel(), device="cuda")
+    moved = run_kernel("v1", q, kc[perm], vc[perm], kv_heads, scale, inv[tables.long()].to(torch.int32), lens, BS, None,
+                       kv_cache)
+    assert torch.equal(moved, v1)
+    # a sequence on its own equals the same sequence inside the batch
+    pick = num_seqs // 3
+    one = run_kernel("v1", q[pick:pick + 1], kc, vc, kv_heads, scale, tables[pick:pick + 1], lens[pick:pick + 1], BS,
+                     None, kv_cache)
+    assert torch.equal(one[0], v1[pick])
+    # and that sequence against the CPU oracle (gathering its blocks only)
+    nblk = -(-int(lens[pick]) // BS)
+    blocks = tables[pick, :nblk].long()
+    ref = oattn.paged_attention(q[pick:pick + 1].cpu(), kc[blocks].cpu(), vc[blocks].cpu(),
+                                torch.arange(nblk, dtype=torch.int32).view(1, -1), lens[pick:pick + 1].cpu(), scale, None)
+    torch.testing.assert_close(v1[pick:pick + 1].cpu().float(), ref.float(), atol=1e-3 if kv_cache == "auto" else 1e-2,
+                               rtol=1e-5)
 
 
 def test_reshape_and_cache_round_trip_and_copy_swap_at_prompt_size():

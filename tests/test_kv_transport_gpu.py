@@ -42,6 +42,16 @@ def test_push_runs_bit_exact_and_rest_untouched():
     for off, n in many:
         expect[off:off + n] = src[off:off + n]
     assert torch.equal(dst2, expect)
+    # a capped launch (the form used over an xGMI link): 3 workgroups walk all 58 chunks of the runs
+    dst3 = before.clone()
+    _C.kv_ops.kv_push(dst3.data_ptr(), src.data_ptr(), [o for o, _ in runs], [n for _, n in runs],
+                      torch.cuda.current_stream().cuda_stream, 3)
+    _C.kv_ops.kv_push(dst3.data_ptr(), src.data_ptr(), [o for o, _ in many], [n for _, n in many],
+                      torch.cuda.current_stream().cuda_stream, 1)
+    torch.cuda.synchronize()
+    for off, n in runs:
+        expect[off:off + n] = src[off:off + n]
+    assert torch.equal(dst3, expect)
     with pytest.raises(RuntimeError, match="16-byte"):
         _C.kv_ops.kv_push(dst.data_ptr(), src.data_ptr(), [8], [16], 0)
     _C.kv_ops.kv_push(dst.data_ptr(), src.data_ptr(), [], [], 0)          # empty: no-op

@@ -12,6 +12,11 @@
 //
 // Synchronisation: per (workgroup, peer) counters that only grow -- call c uses the values
 // 3c+1, 3c+2, 3c+3 -- so nothing is ever reset and a late peer cannot see a stale "ready".
+// The call number c lives on the device, one word per workgroup index in the rank's own signal
+// area, read at the start of a launch and advanced at its end: a launch carries no per-call
+// argument, so it can be captured into a HIP graph and replayed (every rank must still issue the
+// same sequence of calls, eager or replayed; workgroup b takes part in the same calls on every
+// rank because the launch geometry depends on the message size only).
 // A barrier is: wait for my own stores, one relaxed system-scope store of the counter into each
 // peer's signal area, spin (bounded) on my own.  Data that crosses ranks never relies on a cache
 // write-back: peers' inputs were produced by earlier kernels (complete, hence in memory), and
@@ -19,6 +24,7 @@
 #include "common.cuh"
 
 #include <algorithm>
+#include <cstddef>
 
 namespace sw {
 namespace {
@@ -30,10 +36,12 @@ constexpr int kArAuxSystem = 17;                    // sc0 | sc1
 
 struct ArSignal {
   int32_t flag[kArMaxBlocks][kArMaxRanks];          // flag[b][r]: last barrier value rank r announced to workgroup b
+  uint32_t calls[kArMaxBlocks];                     // calls[b]: launches workgroup b of THIS rank has completed
   int32_t status;                                   // 1 + peer rank once a bounded wait ran out
   int32_t pad[63];
 };
-static_assert(sizeof(ArSignal) == 2304, "the signal area's size is part of the ABI");
+static_assert(sizeof(ArSignal) == 2560, "the signal area's size is part of the ABI");
+static_assert(offsetof(ArSignal, status) == sizeof(ArSignal) - 256, "callers read the status word 256 bytes before the end");
 
 struct ArPeers {
   char* base[kArMaxRanks];                          // each rank's exported allocation as mapped here
@@ -43,7 +51,6 @@ struct ArState {
   ArPeers peers;
   int rank, world;
   int64_t signal_off, scratch_off, staging_off, max_bytes;
-  uint32_t calls;
 };
 
 using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
@@ -120,6 +127,22 @@ __device__ __forceinline__ void ar_barrier(const ArPeers& peers, int64_t signal_
   __syncthreads();
 }
 
+// First barrier value of this launch for workgroup blockIdx.x (uniform over the workgroup).
+__device__ __forceinline__ int32_t ar_call_value(const ArPeers& peers, int64_t signal_off, int rank) {
+  const ArSignal* mine = reinterpret_cast<const ArSignal*>(peers.base[rank] + signal_off);
+  const uint32_t c = __hip_atomic_load(&mine->calls[blockIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return (int32_t)(3u * c + 1u);
+}
+
+// After the launch's last barrier: the next launch of this workgroup index uses the next values.
+__device__ __forceinline__ void ar_call_done(const ArPeers& peers, int64_t signal_off, int rank, int32_t value) {
+  if (threadIdx.x == 0) {
+    ArSignal* mine = reinterpret_cast<ArSignal*>(peers.base[rank] + signal_off);
+    __hip_atomic_store(&mine->calls[blockIdx.x], ((uint32_t)value - 1u) / 3u + 1u, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 template <int NR>
 struct Rsrcs {
   __amdgpu_buffer_rsrc_t r[NR];
@@ -147,7 +170,8 @@ __device__ __forceinline__ u32x4 packed_sum(const Rsrcs<NR>& src, int idx) {
 template <typename T, int NR>
 __global__ void __launch_bounds__(kArThreads)
 all_reduce_1stage_kernel(ArPeers peers, int64_t signal_off, int64_t staging_off, u32x4* __restrict__ out, int rank,
-                         int n_vec, int32_t value, long long max_spins) {
+                         int n_vec, long long max_spins) {
+  const int32_t value = ar_call_value(peers, signal_off, rank);
   Rsrcs<NR> src;
 #pragma unroll
   for (int i = 0; i < NR; ++i)
@@ -156,12 +180,14 @@ all_reduce_1stage_kernel(ArPeers peers, int64_t signal_off, int64_t staging_off,
   for (int idx = blockIdx.x * kArThreads + threadIdx.x; idx < n_vec; idx += gridDim.x * kArThreads)
     out[idx] = packed_sum<T, NR>(src, idx);
   ar_barrier<NR>(peers, signal_off, rank, value + 1, max_spins);       // nobody still reads my input
+  ar_call_done(peers, signal_off, rank, value);
 }
 
 template <typename T, int NR>
 __global__ void __launch_bounds__(kArThreads)
 all_reduce_2stage_kernel(ArPeers peers, int64_t signal_off, int64_t scratch_off, int64_t staging_off,
-                         u32x4* __restrict__ out, int rank, int n_vec, int32_t value, long long max_spins) {
+                         u32x4* __restrict__ out, int rank, int n_vec, long long max_spins) {
+  const int32_t value = ar_call_value(peers, signal_off, rank);
   const int part = n_vec / NR;
   const int start = rank * part;
   const int end = rank == NR - 1 ? n_vec : start + part;
@@ -189,31 +215,32 @@ all_reduce_2stage_kernel(ArPeers peers, int64_t signal_off, int64_t scratch_off,
     }
   }
   ar_barrier<NR>(peers, signal_off, rank, value + 2, max_spins);       // nobody still reads my scratch or input
+  ar_call_done(peers, signal_off, rank, value);
 }
 
 template <typename T, int NR>
-int launch_all_reduce(ArState* st, void* out, int n_vec, bool two_stage, int32_t value, hipStream_t stream) {
+int launch_all_reduce(ArState* st, void* out, int n_vec, bool two_stage, hipStream_t stream) {
   const int blocks = std::min(36, (n_vec + kArThreads - 1) / kArThreads);
   const long long max_spins = 20LL * 1000 * 1000;                     // a lost peer ends the wait after seconds
   if (two_stage)
     all_reduce_2stage_kernel<T, NR><<<blocks, kArThreads, 0, stream>>>(st->peers, st->signal_off, st->scratch_off,
                                                                       st->staging_off, static_cast<u32x4*>(out),
-                                                                      st->rank, n_vec, value, max_spins);
+                                                                      st->rank, n_vec, max_spins);
   else
     all_reduce_1stage_kernel<T, NR><<<blocks, kArThreads, 0, stream>>>(st->peers, st->signal_off, st->staging_off,
                                                                       static_cast<u32x4*>(out), st->rank, n_vec,
-                                                                      value, max_spins);
+                                                                      max_spins);
   SW_CHECK_LAUNCH();
   return SW_OK;
 }
 
 template <typename T>
-int dispatch_world(ArState* st, void* out, int n_vec, bool two_stage, int32_t value, hipStream_t stream) {
+int dispatch_world(ArState* st, void* out, int n_vec, bool two_stage, hipStream_t stream) {
   switch (st->world) {
-    case 2: return launch_all_reduce<T, 2>(st, out, n_vec, two_stage, value, stream);
-    case 4: return launch_all_reduce<T, 4>(st, out, n_vec, two_stage, value, stream);
-    case 6: return launch_all_reduce<T, 6>(st, out, n_vec, two_stage, value, stream);
-    case 8: return launch_all_reduce<T, 8>(st, out, n_vec, two_stage, value, stream);
+    case 2: return launch_all_reduce<T, 2>(st, out, n_vec, two_stage, stream);
+    case 4: return launch_all_reduce<T, 4>(st, out, n_vec, two_stage, stream);
+    case 6: return launch_all_reduce<T, 6>(st, out, n_vec, two_stage, stream);
+    case 8: return launch_all_reduce<T, 8>(st, out, n_vec, two_stage, stream);
     default: break;
   }
   set_error("custom all-reduce only supports 2, 4, 6 or 8 ranks (got %d)", st->world);
@@ -253,7 +280,6 @@ int sw_custom_ar_init(void** peer_bases, int rank, int world, int64_t signal_off
   st->scratch_off = scratch_off;
   st->staging_off = staging_off;
   st->max_bytes = max_bytes;
-  st->calls = 0;
   *state_out = st;
   return SW_OK;
 }
@@ -277,12 +303,10 @@ int sw_custom_all_reduce(void* state, const void* input, void* output, int64_t n
   if (algorithm == 1) two_stage = false;
   if (algorithm == 2) two_stage = st->world > 1;
   if (n_vec < st->world) two_stage = false;
-  const int32_t value = (int32_t)(3u * st->calls + 1u);
-  st->calls += 1;
   switch (act_dtype) {
-    case SW_F32: return dispatch_world<float>(st, output, n_vec, two_stage, value, s);
-    case SW_F16: return dispatch_world<f16_t>(st, output, n_vec, two_stage, value, s);
-    case SW_BF16: return dispatch_world<bf16_t>(st, output, n_vec, two_stage, value, s);
+    case SW_F32: return dispatch_world<float>(st, output, n_vec, two_stage, s);
+    case SW_F16: return dispatch_world<f16_t>(st, output, n_vec, two_stage, s);
+    case SW_BF16: return dispatch_world<bf16_t>(st, output, n_vec, two_stage, s);
     default: break;
   }
   set_error("custom_all_reduce: unsupported data type %d", act_dtype);

@@ -35,10 +35,13 @@ using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
 // Stores go out write-through at system scope (sc0 sc1): the bytes leave this GPU's caches as
 // they are issued, so no cache write-back is needed before the hand-off flag is raised; each
 // wave only drains its own store queue before it retires.
+// A workgroup walks the chunks blockIdx.x, blockIdx.x + gridDim.x, ...: the grid may be capped to the
+// few workgroups one xGMI link can keep busy, so that a push running beside a layer's attention (on
+// its own stream) does not park thousands of workgroups on link-bound stores.
 __global__ void __launch_bounds__(kPushThreads)
-kv_push_kernel(char* __restrict__ dst_base, const char* __restrict__ src_base, PushRuns runs) {
-  const int chunk = blockIdx.x;
+kv_push_kernel(char* __restrict__ dst_base, const char* __restrict__ src_base, PushRuns runs, int num_chunks) {
   int r = 0;
+  for (int chunk = blockIdx.x; chunk < num_chunks; chunk += gridDim.x) {
   while (r + 1 < runs.num_runs && chunk >= runs.first_chunk[r + 1]) ++r;
   const int64_t begin = (int64_t)(chunk - runs.first_chunk[r]) * kChunkBytes;
   const int64_t end = min(begin + kChunkBytes, runs.nbytes[r]);
@@ -63,6 +66,7 @@ kv_push_kernel(char* __restrict__ dst_base, const char* __restrict__ src_base, P
   for (; i < n; i += kPushThreads) {
     const uint4 a = src[i];
     __builtin_amdgcn_raw_buffer_store_b128(u32x4{a.x, a.y, a.z, a.w}, rsrc, i * 16, 0, kAuxSystem);
+  }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
@@ -132,7 +136,7 @@ int sw_ipc_close_mem_handle(void* dev_ptr) {
 }
 
 int sw_kv_push(void* dst_base, const void* src_base, const int64_t* offsets, const int64_t* nbytes,
-               int num_runs, void* stream) {
+               int num_runs, int max_workgroups, void* stream) {
   using namespace sw;
   if (num_runs == 0) return SW_OK;
   SW_CHECK_ARG(dst_base && src_base && offsets && nbytes && num_runs > 0, "kv_push: bad arguments");
@@ -157,8 +161,9 @@ int sw_kv_push(void* dst_base, const void* src_base, const int64_t* offsets, con
     }
     runs.first_chunk[n] = chunks;
     runs.num_runs = n;
-    kv_push_kernel<<<chunks, kPushThreads, 0, s>>>(static_cast<char*>(dst_base),
-                                                   static_cast<const char*>(src_base), runs);
+    const int grid = max_workgroups > 0 ? std::min(chunks, max_workgroups) : chunks;
+    kv_push_kernel<<<grid, kPushThreads, 0, s>>>(static_cast<char*>(dst_base),
+                                                 static_cast<const char*>(src_base), runs, chunks);
     SW_CHECK_LAUNCH();
     done += n;
   }

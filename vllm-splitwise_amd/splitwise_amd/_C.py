@@ -63,7 +63,7 @@ _SIGNATURES = {
     "sw_mem_address_range": [_c_void_p, ctypes.POINTER(_c_void_p), ctypes.POINTER(_c_i64)],
     "sw_ipc_open_mem_handle": [_c_void_p, ctypes.POINTER(_c_void_p)],
     "sw_ipc_close_mem_handle": [_c_void_p],
-    "sw_kv_push": [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p],
+    "sw_kv_push": [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_void_p],
     "sw_kv_signal": [_c_void_p, _c_int, ctypes.c_int32, _c_void_p],
     "sw_kv_wait": [_c_void_p, _c_int, ctypes.c_int32, _c_i64, _c_void_p, _c_void_p],
     "sw_context_attention": [_c_void_p] * 7 + [_c_int] + [_c_void_p] * 3 + [_c_int] * 6 + [ctypes.c_float, _c_void_p]
@@ -97,7 +97,7 @@ def library_path() -> str:
     return _LIB_PATH
 
 
-ABI_VERSION = 3                # SW_ABI_VERSION of include/splitwise_hip.h this binding was written against
+ABI_VERSION = 4                # SW_ABI_VERSION of include/splitwise_hip.h this binding was written against
 
 
 def load_library() -> ctypes.CDLL:
@@ -520,13 +520,15 @@ def custom_ar_dispose(state: int) -> None:
     _check(load_library().sw_custom_ar_dispose(state))
 
 
-def kv_push(dst_base: int, src_base: int, offsets: List[int], nbytes: List[int], stream: int) -> None:
+def kv_push(dst_base: int, src_base: int, offsets: List[int], nbytes: List[int], stream: int,
+            max_workgroups: int = 0) -> None:
     n = len(offsets)
     if n == 0:
         return
     off = (ctypes.c_int64 * n)(*offsets)
     nb = (ctypes.c_int64 * n)(*nbytes)
-    _check(load_library().sw_kv_push(dst_base, src_base, ctypes.addressof(off), ctypes.addressof(nb), n, stream))
+    _check(load_library().sw_kv_push(dst_base, src_base, ctypes.addressof(off), ctypes.addressof(nb), n,
+                                     int(max_workgroups), stream))
 
 
 def kv_signal(flags_ptr: int, slot: int, epoch: int, stream: int) -> None:

@@ -25,7 +25,7 @@ def _kv_push_bandwidth(executor, iters: int = 6):
     num_layers = len(worker.gpu_cache)
     num_blocks = min(128, worker.cache_config.num_gpu_blocks)
     per_iter = 2 * num_layers * num_blocks * comm.block_size
-    stream = torch.cuda.current_stream(worker.device)
+    stream = comm.push_stream                  # where the pushes run
 
     def one():
         for layer in range(num_layers):

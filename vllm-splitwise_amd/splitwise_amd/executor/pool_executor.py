@@ -61,8 +61,7 @@ class PoolExecutor(ExecutorBase):
         self.tp = parallel_config.tensor_parallel_size
         self.split = parallel_config.sep_prompt_token
         self.world = parallel_config.world_size
-        if self.tp > 1 and not model_config.enforce_eager:
-            # collectives inside captured HIP graphs are not exercised by this build
+        if self.tp > 1 and not model_config.enforce_eager and not self._collectives_capturable():
             model_config.enforce_eager = True
         if devices is None:
             n = max(torch.cuda.device_count(), 1)
@@ -102,6 +101,22 @@ class PoolExecutor(ExecutorBase):
             # do not talk to them, end them
             self.shutdown(graceful=False)
             raise
+
+    def _collectives_capturable(self) -> bool:
+        """Decode graphs of tensor-parallel ranks hold the layer's all-reduces: that works when every one
+        of them goes through the peer-read kernel (its launches carry no per-call host state), i.e. the
+        group size is one it supports, it is not switched off, and the largest captured batch's
+        [rows, hidden] message fits its buffer.  The reference captures its collectives through cupy's
+        NCCL binding or the registered-buffer form of its custom kernel (model_runner.py:701-760,
+        custom_all_reduce.py:188-234)."""
+        from ..model_executor.custom_all_reduce import _MAX_SIZE, _SUPPORTED_WORLD_SIZES
+        if self.tp not in _SUPPORTED_WORLD_SIZES or getattr(self.parallel_config, "disable_custom_all_reduce", False):
+            return False
+        hidden = self.model_config.hf_config["hidden_size"]
+        elt = torch.tensor([], dtype=self.model_config.dtype).element_size()
+        rows = min(256, max(self.scheduler_config.max_num_seqs, 1))
+        rows = 1 << (rows - 1).bit_length() if rows <= 8 else -(-rows // 8) * 8      # padded graph batch
+        return rows * hidden * elt <= _MAX_SIZE
 
     def _remote_cfg(self, rank: int, init_method: Optional[str]) -> Dict[str, Any]:
         return {"model_config": self.model_config, "parallel_config": self.parallel_config,

@@ -8,7 +8,11 @@ Interface of vllm/model_executor/parallel_utils/custom_all_reduce.py:27-234 (``i
 restricts itself to NVLink-connected CUDA devices and is compiled out on ROCm
 (csrc/pybind.cpp:113-127); here the only requirement is that the peers' memory can be mapped.
 
-Graph capture is not supported by this class: tensor-parallel workers run eager steps.
+Graph capture: a launch carries no per-call host state (the barrier values come from counters on the
+device), so ``all_reduce_unreg`` may be captured into a HIP graph and replayed -- the staging copy
+becomes a copy node in front of the kernel.  Where the reference registers the addresses of a
+captured graph's buffers with its peers afterwards (custom_all_reduce.py:188-213), nothing is
+needed here: peers only ever read the staging area, whose address never changes.
 """
 from typing import List, Optional
 
@@ -18,6 +22,7 @@ import torch.distributed as dist
 from .. import _C
 
 _SUPPORTED_WORLD_SIZES = (2, 4, 6, 8)
+_MAX_SIZE = 8192 * 1024          # largest message in bytes (custom_all_reduce.py:148-149)
 _HANDLE: Optional["CustomAllreduce"] = None
 
 
@@ -26,8 +31,7 @@ def _align(n: int, a: int) -> int:
 
 
 class CustomAllreduce:
-    # max_size: largest message in bytes (custom_all_reduce.py:148-149)
-    def __init__(self, rank: int, world_size: int, group=None, max_size: int = 8192 * 1024,
+    def __init__(self, rank: int, world_size: int, group=None, max_size: int = _MAX_SIZE,
                  device: Optional[torch.device] = None) -> None:
         if world_size not in _SUPPORTED_WORLD_SIZES:
             raise ValueError(f"custom all-reduce supports {_SUPPORTED_WORLD_SIZES} ranks, not {world_size}")

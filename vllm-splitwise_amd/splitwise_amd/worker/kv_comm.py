@@ -16,6 +16,7 @@ kernel); it exists as a fallback should direct peer stores from a kernel misbeha
 system.  (Inter-process HIP events are not usable for the hand-off: hipIpcGetEventHandle
 fails on this stack.)
 """
+import os
 import threading
 from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
@@ -106,7 +107,7 @@ class KVCacheCommunicator:
     """The data path once both sides are connected (comm_utils.py:90-147)."""
 
     def __init__(self, block_size: int, layer_offsets: List[Tuple[int, int]], local_base: int, peer_base: int,
-                 flags_offset: int, transport: str, device: torch.device) -> None:
+                 flags_offset: int, transport: str, device: torch.device, peer_is_remote: bool = True) -> None:
         self.block_size = block_size                  # bytes of one block of one tensor
         self.layer_offsets = layer_offsets
         self.local_base = local_base
@@ -121,15 +122,36 @@ class KVCacheCommunicator:
         # wait kernel stores to directly, so the worker can look at it after every step's own
         # synchronisation (the copy of the sampled tokens) without another device round trip
         self.status_host = torch.zeros(1, dtype=torch.int32).pin_memory()
-        import os
         # polls before a wait gives up (read once, at set-up; tests shorten it)
         self.max_spins = int(os.environ.get("SPLITWISE_KV_WAIT_SPINS", _MAX_SPINS))
+        # Pushes and signals run on a stream of their own: a layer's push waits (on the device) for that
+        # layer's cache write and then moves bytes while the compute stream goes on with the layer's
+        # attention and the next layers; the signal is enqueued behind the step's last push.  Over one
+        # xGMI link a 772-token prompt is milliseconds of link time: on the compute stream it would
+        # stall every layer behind link-bound stores.
+        self.push_stream = torch.cuda.Stream(device) if device.type == "cuda" else None
+        # workgroups of one push launch: a link is filled by a few dozen, a device-local copy (both
+        # workers on one GPU: tests, rehearsals) wants one per 64 KiB chunk
+        self.push_workgroups = int(os.environ.get("SPLITWISE_KV_PUSH_WORKGROUPS", "32" if peer_is_remote else "0"))
         # runtime transport state
         self.local_bytes: Optional[torch.Tensor] = None
         self.peer_bytes: Optional[torch.Tensor] = None
 
     def _stream(self) -> int:
         return torch.cuda.current_stream(self.device).cuda_stream
+
+    def _after_compute(self) -> "torch.cuda.Stream":
+        """The push stream, made to wait for everything enqueued on the compute stream so far (the
+        cache write of the layer whose blocks are about to be pushed)."""
+        event = torch.cuda.Event()
+        event.record(torch.cuda.current_stream(self.device))
+        self.push_stream.wait_event(event)
+        return self.push_stream
+
+    def synchronize(self) -> None:
+        """Host wait for every push and signal issued so far."""
+        if self.push_stream is not None:
+            self.push_stream.synchronize()
 
     def put_many(self, layer_id: int, runs: Sequence[Tuple[int, int]]) -> None:
         """All (block_start, num_blocks) runs of one layer, K and V, in one launch."""
@@ -142,11 +164,14 @@ class KVCacheCommunicator:
                 offsets.append(base + block_start * self.block_size)
                 sizes.append(num_blocks * self.block_size)
         self.bytes_pushed += sum(sizes)
+        stream = self._after_compute()
         if self.transport == "kernel":
-            _C.kv_ops.kv_push(self.peer_base, self.local_base, offsets, sizes, self._stream())
+            _C.kv_ops.kv_push(self.peer_base, self.local_base, offsets, sizes, stream.cuda_stream,
+                              self.push_workgroups)
         else:
-            for off, n in zip(offsets, sizes):
-                self.peer_bytes[off:off + n].copy_(self.local_bytes[off:off + n], non_blocking=True)
+            with torch.cuda.stream(stream):
+                for off, n in zip(offsets, sizes):
+                    self.peer_bytes[off:off + n].copy_(self.local_bytes[off:off + n], non_blocking=True)
 
     def put(self, sem_id: int, layer_id: int, block_start: int, num_blocks: int) -> None:
         del sem_id                                    # ordering is by stream, not by channel
@@ -156,12 +181,17 @@ class KVCacheCommunicator:
         if epoch is None:
             epoch = self.signal_epoch[sem_id] + 1
         self.signal_epoch[sem_id] = epoch
+        # on the push stream, behind every push of the step (each of which waited for its layer's cache
+        # write): the hand-off is announced when the last layer's blocks have left, not when the
+        # prompt step's remaining layers, logits and sampling are over
         if self.transport == "kernel":
-            _C.kv_ops.kv_signal(self.peer_base + self.flags_offset, sem_id, epoch, self._stream())
+            _C.kv_ops.kv_signal(self.peer_base + self.flags_offset, sem_id, epoch, self.push_stream.cuda_stream)
         else:
             word = torch.tensor([epoch], dtype=torch.int32, device=self.device).view(torch.uint8)
             off = self.flags_offset + 4 * sem_id
-            self.peer_bytes[off:off + 4].copy_(word, non_blocking=True)      # after the data copies, in stream order
+            with torch.cuda.stream(self._after_compute()):               # `word` was made on the compute stream
+                self.peer_bytes[off:off + 4].copy_(word, non_blocking=True)      # after the data copies, in stream order
+            word.record_stream(self.push_stream)
 
     def wait(self, sem_id: int, epoch: Optional[int] = None) -> None:
         if epoch is None:
@@ -239,7 +269,9 @@ class KVCacheCommManager:
                               "mapping the token worker's KV cache (hipIpcOpenMemHandle)")
             self._peer_mapping = mapped
             peer_base = mapped + peer["offset"]
-        comm = KVCacheCommunicator(block_bytes, layer_offsets, base, peer_base, flags_offset, self.transport, device)
+        remote = tuple(peer.get("pid_device", ())) != (torch.cuda.current_device(),)
+        comm = KVCacheCommunicator(block_bytes, layer_offsets, base, peer_base, flags_offset, self.transport, device,
+                                   peer_is_remote=remote)
         if self.transport == "runtime":
             comm.local_bytes = slab
             if self.is_prompt_side:
@@ -260,7 +292,7 @@ class KVCacheCommManager:
         comm = self.kvcache_comm
         if comm is None or self._slab is None:
             return
-        torch.cuda.synchronize(comm.device)
+        torch.cuda.synchronize(comm.device)            # every stream of the device, the push stream included
         comm.check_status()
 
     def check_status_after_step(self) -> None:

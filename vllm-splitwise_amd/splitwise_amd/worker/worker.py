@@ -148,9 +148,13 @@ class Worker:
         self.model_runner.set_block_size(self.cache_engine.block_size)
 
     def warm_up_model(self) -> None:
-        if not self.model_config.enforce_eager:
+        # decode graphs; a prompt-pool worker never decodes
+        if not self.model_config.enforce_eager and not self.is_prompt_worker():
             self.model_runner.capture_model(self.gpu_cache)
         torch.manual_seed(self.model_config.seed)
+
+    def num_captured_graphs(self) -> int:
+        return len(self.model_runner.graph_runners)
 
     def setup_kvcache_comm(self) -> None:
         if self.kvcache_comm_manager is None:
