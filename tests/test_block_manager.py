@@ -149,3 +149,122 @@ def test_block_numbers_are_fresh_first_then_first_freed_first():
     d, gd = _prompt("d", 4)
     mgr.allocate(gd)
     assert mgr.get_block_table(d) == [1]
+
+
+# ---------------------------------------------------------------- prefix caching
+def test_caching_pool_shares_blocks_by_hash_and_revives_freed_ones():
+    """Scenario and answers of the reference's tests/prefix_caching/test_prefix_caching.py:13-43."""
+    from splitwise_amd.core.block_manager import CachingBlockPool
+    from splitwise_amd.utils import Device
+    pool = CachingBlockPool(Device.CPU, 16, 16)
+    first = pool.allocate(1, 0)
+    second = pool.allocate(1, 0)
+    assert first == second and pool.ref_count(second) == 2
+    pool.free(first)
+    assert pool.ref_count(second) == 1
+    pool.free(second)
+    again = pool.allocate(1, 0)                      # its count went to 0, yet the same block comes back
+    assert again == second and pool.block_hash[again] == 1
+
+
+def test_caching_pool_evicts_the_least_recently_used_block():
+    """tests/prefix_caching/test_prefix_caching.py:46-85."""
+    from splitwise_amd.core.block_manager import CachingBlockPool
+    from splitwise_amd.utils import Device
+    num_blocks, block_size = 16, 16
+    pool = CachingBlockPool(Device.CPU, block_size, num_blocks)
+    blocks = [pool.allocate(i, 0) for i in range(num_blocks)]
+    for block in blocks:
+        pool.free(block)
+    new = pool.allocate(block_size, 0)
+    assert new == blocks[0] and pool.block_hash[new] == block_size       # the first one freed
+    realloc = pool.allocate(1, 0)                                         # taken back out of the free list
+    assert realloc == blocks[1] and pool.block_hash[realloc] == 1
+    new = pool.allocate(block_size + 1, 0)
+    assert new != realloc and pool.block_hash[new] == block_size + 1 and new == 2
+
+
+def test_eviction_prefers_older_blocks_then_the_one_that_hashes_more_tokens():
+    """vllm/core/evictor.py:68-104."""
+    from splitwise_amd.core.block_manager import CachingBlockPool
+    from splitwise_amd.utils import Device
+    pool = CachingBlockPool(Device.GPU, 4, 3)
+    a, b, c = pool.allocate(10, 4), pool.allocate(11, 8), pool.allocate(12, 12)
+    pool.last_accessed[a], pool.last_accessed[b], pool.last_accessed[c] = 5.0, 3.0, 3.0
+    pool.computed[c] = True
+    for block in (a, b, c):
+        pool.free(block)
+    assert pool.allocate(20, 4) == c and not pool.computed[c]            # oldest stamp, most hashed tokens
+    assert pool.allocate(21, 4) == b
+    assert pool.allocate(22, 4) == a
+    with pytest.raises(ValueError, match="No usable cache memory left"):
+        pool.allocate(23, 4)
+
+
+def test_prompts_with_a_common_prefix_share_blocks_and_report_them_computed():
+    """block_manager.py:199-201 (allocation by content hash), :441-487 (computed blocks): the second prompt
+    gets the first one's full blocks, and may skip those that have been marked computed -- which, as the
+    reference writes it (:441-451), are the full blocks of a sequence except the last full one."""
+    bm = BlockSpaceManager(4, 16, 16, watermark=0, enable_caching=True)
+    prefix = list(range(100, 114))                                        # 3 full blocks + 2 tokens
+    a = Sequence(1, None, prefix + [1], 4)                                # the fourth block holds 3 of 4 tokens
+    ga = SequenceGroup("a", [a], SamplingParams(), time.time())
+    bm.allocate(ga)
+    a.status = SequenceStatus.RUNNING
+    assert bm.get_common_computed_block_ids(ga) == []                     # nothing has been computed yet
+    bm.mark_blocks_as_computed(ga)                                        # the prompt step has run
+    b = Sequence(2, None, prefix + [7, 8, 9], 4)
+    gb = SequenceGroup("b", [b], SamplingParams(), time.time())
+    bm.allocate(gb)
+    ta, tb = bm.get_block_table(a), bm.get_block_table(b)
+    assert ta[:3] == tb[:3] and ta[3] != tb[3]                            # the block where they diverge is private
+    assert bm.get_common_computed_block_ids(gb) == tb[:2]
+    assert bm.gpu_allocator.ref_count(ta[0]) == 2
+    # an identical prompt shares every block, the partly filled last one too
+    c = Sequence(3, None, prefix + [1], 4)
+    gc = SequenceGroup("c", [c], SamplingParams(), time.time())
+    bm.allocate(gc)
+    assert bm.get_block_table(c) == ta and bm.gpu_allocator.ref_count(ta[3]) == 2
+    assert bm.get_common_computed_block_ids(gc) == ta[:2]
+    # the first append to the shared last block copies it
+    c.status = SequenceStatus.RUNNING
+    _append(c, 5)
+    src_dst = bm.append_slot(c)
+    assert src_dst is not None and src_dst[0] == ta[3] and bm.get_block_table(c)[3] == src_dst[1]
+    for seq in (a, b, c):
+        bm.free(seq)
+    assert bm.get_num_free_gpu_blocks() == 16
+    # freed blocks stay findable: the same prefix comes back on the same blocks, still computed
+    d = Sequence(4, None, prefix + [3], 4)
+    gd = SequenceGroup("d", [d], SamplingParams(), time.time())
+    bm.allocate(gd)
+    assert bm.get_block_table(d)[:3] == ta[:3] and bm.get_common_computed_block_ids(gd) == ta[:2]
+    # a prompt that is cached completely still runs its last block
+    e = Sequence(5, None, prefix[:8], 4)
+    ge = SequenceGroup("e", [e], SamplingParams(), time.time())
+    bm.allocate(ge)
+    assert bm.get_block_table(e) == ta[:2] and bm.get_common_computed_block_ids(ge) == ta[:1]
+
+
+def test_a_block_that_fills_up_is_promoted_to_its_content_hash():
+    """block_manager.py:218-252: two sequences that grow into the same content end up on one block."""
+    bm = BlockSpaceManager(4, 16, 16, watermark=0, enable_caching=True)
+    seqs = []
+    for i in (1, 2):
+        s = Sequence(i, None, [9, 9, 9, 9, 5] if i == 1 else [9, 9, 9, 9, 5, 6], 4)
+        g = SequenceGroup(str(i), [s], SamplingParams(), time.time())
+        bm.allocate(g)
+        s.status = SequenceStatus.RUNNING
+        seqs.append(s)
+    s1, s2 = seqs
+    assert bm.get_block_table(s1)[0] == bm.get_block_table(s2)[0]
+    assert bm.get_block_table(s1)[1] != bm.get_block_table(s2)[1]         # different partial contents
+    for tok in (6, 7, 8):
+        _append(s1, tok)
+        assert bm.append_slot(s1) is None
+    for tok in (7, 8):
+        _append(s2, tok)
+        assert bm.append_slot(s2) is None
+    # both second blocks now hold 5 6 7 8 after the same first block: one physical block
+    assert bm.get_block_table(s1)[1] == bm.get_block_table(s2)[1]
+    assert bm.gpu_allocator.ref_count(bm.get_block_table(s1)[1]) == 2

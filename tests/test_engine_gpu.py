@@ -63,6 +63,47 @@ def test_greedy_generation_matches_cpu_model(model, enforce_eager):
     torch.cuda.empty_cache()
 
 
+@pytest.mark.parametrize("sep,pipeline", [(False, False), (False, True), (True, False)])
+def test_prefix_caching_reuses_blocks_and_generates_like_the_cpu_model(sep, pipeline, monkeypatch):
+    """enable_prefix_caching: prompts that start with the same tokens share KV blocks; once those are computed a
+    later prompt runs only its remaining tokens, through the prefix-aware prompt kernel over the paged
+    context.  The tokens must still be the CPU model's (which knows nothing of caches), co-located, with
+    pipelined steps, and with a prompt worker pushing to a token worker."""
+    from splitwise_amd import LLM, SamplingParams, _C
+    random.seed(7)
+    llm = LLM("llama-tiny", enable_prefix_caching=True, enforce_eager=True, num_gpu_blocks_override=96,
+              max_num_seqs=8, max_model_len=512, swap_space=0.01, sep_prompt_token=sep, pipeline_steps=pipeline)
+    calls = {"prefix": 0}
+    orig = _C.ops.context_attention_fwd
+
+    def counting(*a, **k):
+        calls["prefix"] += 1
+        return orig(*a, **k)
+
+    monkeypatch.setattr(_C.ops, "context_attention_fwd", counting)
+    try:
+        vocab = llm.llm_engine.model_config.get_vocab_size()
+        shared = [random.randrange(vocab) for _ in range(150)]               # 9 full blocks of 16 + 6 tokens
+        first = [shared + [random.randrange(vocab) for _ in range(n)] for n in (3, 40)]
+        params = SamplingParams(temperature=0.0, max_tokens=12)
+        outs1 = llm.generate(prompt_token_ids=first, sampling_params=params)
+        assert calls["prefix"] == 0 or sep is False                           # nothing was computed before them
+        before = calls["prefix"]
+        second = [shared + [random.randrange(vocab) for _ in range(n)] for n in (1, 17, 64)] + \
+                 [[random.randrange(vocab) for _ in range(30)], first[0]]     # an unrelated one, and a repeat
+        outs2 = llm.generate(prompt_token_ids=second, sampling_params=params)
+        layers = llm.llm_engine.model_config.hf_config["num_hidden_layers"]
+        assert calls["prefix"] - before >= layers, "no prompt step of the second round used the cached prefix"
+        bm = llm.llm_engine.scheduler.block_manager
+        assert bm.get_num_free_gpu_blocks() == 96
+        _check_greedy(llm, first + second, list(outs1) + list(outs2), tol=3e-2)
+    finally:
+        if sep:
+            llm.llm_engine.model_executor.shutdown()
+        del llm
+        torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("quantization", ["gptq", "awq"])
 def test_int4_models_match_cpu_model(quantization):
     """Llama geometry with every linear layer in int4 (random words, group size 128): the engine's

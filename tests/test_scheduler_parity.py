@@ -140,3 +140,95 @@ def test_scheduler_trace_matches_reference(name):
         assert finished == rec["finished"]
         if pool._next_fresh >= pool.num_blocks:
             blocks_exact = False
+
+
+def test_prefix_caching_trace_matches_reference():
+    """Scheduler + BlockSpaceManager(enable_caching=True) + _prepare_prompt over cached prefixes, step by step
+    against the reference's own run (tools/gen_golden.py gen_prefix_caching): shared prompt blocks, computed
+    block lists, blocks revived from the evictor, least-recently-used eviction once the pool is full.
+    Everything that does not name a physical block is compared exactly throughout.  Block numbers are compared
+    exactly until the first EVICTION: from there the reference's choice among blocks of equal age and
+    equal hashed-token count depends on the iteration order of a set of Python objects
+    (vllm/core/block_manager.py:401-414), so tables are checked for shape and consistency instead."""
+    trace = load("scheduler_prefix_caching.json")
+    bs = trace["block_size"]
+    sched_cfg = SchedulerConfig(trace["max_num_batched_tokens"], trace["max_num_seqs"],
+                                trace["max_num_batched_tokens"], max_paddings=trace["max_paddings"])
+    cache_cfg = CacheConfig(bs, 1.0, 1, "auto", enable_prefix_caching=True)
+    cache_cfg.num_gpu_blocks = trace["num_gpu_blocks"]
+    cache_cfg.num_cpu_blocks = trace["num_gpu_blocks"]
+    sched = Scheduler(sched_cfg, cache_cfg, None, track_prompt_blocks=True, strict_reference=True)
+    runner = ModelRunner(None, None, None, DeviceConfig("cpu"))
+    runner.set_block_size(bs)
+    lifetimes = {int(k): v for k, v in trace["lifetimes"].items()}
+    pool = sched.block_manager.gpu_allocator
+    seqs = {}
+    t = 0.0
+    exact_steps = 0
+    evicted_yet = False
+    for rec in trace["steps"]:
+        for rid, tokens in rec["arrivals"]:
+            t += 1.0
+            seq = Sequence(rid, "", list(tokens), bs)
+            group = SequenceGroup(str(rid), [seq], SamplingParams(temperature=0.0, max_tokens=10 ** 6), t)
+            seqs[str(rid)] = (group, seq)
+            sched.add_seq_group(group)
+        fresh_before = pool.current_num_blocks
+        free_before = len(pool.free_table)
+        metas, outs = sched.schedule()
+        # an eviction = a block handed out when no fresh one was left
+        evicted = fresh_before == pool.num_blocks and len(pool.free_table) < free_before
+        evicted_yet = evicted_yet or evicted
+        blocks_exact = not evicted_yet
+        step = rec["step"]
+        assert bool(outs.prompt_run) == rec["prompt_run"], step
+        assert [m.request_id for m in metas] == rec["scheduled"], step
+        assert [g.request_id for g in sched.waiting] == rec["waiting"], step
+        assert [g.request_id for g in sched.running] == rec["running"], step
+        assert sched.block_manager.get_num_free_gpu_blocks() == rec["free_gpu_blocks"], step
+        tables = {m.request_id: list(next(iter(m.block_tables.values()))) for m in metas}
+        computed = {m.request_id: list(m.computed_block_nums or []) for m in metas}
+        assert {k: len(v) for k, v in tables.items()} == {k: len(v) for k, v in rec["block_tables"].items()}, step
+        assert {k: len(v) for k, v in computed.items()} == {k: len(v) for k, v in rec["computed_block_nums"].items()}, step
+        for rid, ids in computed.items():
+            assert ids == tables[rid][:len(ids)]                   # a leading run of the table, never all of it
+            assert len(ids) < len(tables[rid])
+        nw = {str(k): [list(r) for r in v] for k, v in outs.blocks_to_nw.items()}
+        assert sorted(nw) == sorted(rec["blocks_to_nw"]), step
+        if blocks_exact:
+            exact_steps += 1
+            assert tables == rec["block_tables"], step
+            assert computed == rec["computed_block_nums"], step
+            assert nw == rec["blocks_to_nw"], step
+            assert {str(k): list(v) for k, v in outs.blocks_to_copy.items()} == rec["blocks_to_copy"], step
+        if metas and outs.prompt_run:
+            ref = rec["inputs"]
+            toks, pos, md, plens, sublens = runner._prepare_prompt(metas)
+            assert toks.tolist() == ref["input_tokens"], step
+            assert pos.tolist() == ref["input_positions"], step
+            assert plens == ref["prompt_lens"] and sublens == ref["subquery_lens"], step
+            assert md.max_seq_len == ref["max_seq_len"] and md.start_loc.tolist() == ref["start_loc"], step
+            assert md.context_lens.tolist() == ref["context_lens"], step
+            assert list(md.block_tables.shape) == [len(ref["block_tables"]), len(ref["block_tables"][0])], step
+            if blocks_exact:
+                assert md.slot_mapping.tolist() == ref["slot_mapping"], step
+                assert md.block_tables.tolist() == ref["block_tables"], step
+            for row, m, ctx in zip(md.slot_mapping.tolist(), metas, md.context_lens.tolist()):
+                table = tables[m.request_id]
+                n = len(next(iter(m.seq_data.values())).get_token_ids())
+                assert row[:n - ctx] == [table[i // bs] * bs + i % bs for i in range(ctx, n)]
+        for m in metas:
+            sched.mark_blocks_as_computed(seqs[m.request_id][0])
+        finished = []
+        for m in metas:
+            group, seq = seqs[m.request_id]
+            tok = 7 + int(m.request_id) % 2
+            seq.append_token_id(tok, {tok: Logprob(0.0)})
+            if seq.get_output_len() >= lifetimes[int(m.request_id)]:
+                seq.status = SequenceStatus.FINISHED_STOPPED
+                sched.free_seq(seq)
+                finished.append(m.request_id)
+        sched.free_finished_seq_groups()
+        assert finished == rec["finished"], step
+    assert exact_steps >= 16        # sharing, promotion onto an existing block and revival are all inside the exact part
+    assert sched.block_manager.get_num_free_gpu_blocks() == trace["num_gpu_blocks"]

@@ -270,6 +270,93 @@ def gen_scheduler():
     _trace_scenario("churn", 16, 40, 6, 128, arrivals, lifetimes)
 
 
+def _trace_prefix_scenario(name, block_size, num_gpu_blocks, max_num_seqs, max_batched, arrivals, lifetimes,
+                           max_steps=200):
+    """Scheduler + BlockSpaceManager(enable_caching=True) + _prepare_prompt with cached prefixes.
+    arrivals: {step: [(request_id, prompt token ids)]}.  After every step the scheduled groups are marked
+    computed, as LLMEngine._process_model_outputs does (vllm/engine/llm_engine.py:543-547)."""
+    sched_cfg = SchedulerConfig(max_batched, max_num_seqs, max_batched, max_paddings=256)
+    cache_cfg = CacheConfig(block_size, 1.0, 1, "auto", enable_prefix_caching=True)
+    cache_cfg.num_gpu_blocks = num_gpu_blocks
+    cache_cfg.num_cpu_blocks = num_gpu_blocks
+    sched = Scheduler(sched_cfg, cache_cfg, None, track_prompt_blocks=True)
+    runner = ModelRunner(None, None, None, DeviceConfig("cpu"), None)
+    runner.set_block_size(block_size)
+    runner.model_config = types.SimpleNamespace(enforce_eager=True)
+    seqs = {}
+    steps = []
+    t = 0.0
+    for step in range(max_steps):
+        for rid, tokens in arrivals.get(step, []):
+            t += 1.0
+            seq = Sequence(int(rid), "", list(tokens), block_size)
+            group = SequenceGroup(str(rid), [seq], SamplingParams(temperature=0.0, max_tokens=10 ** 6), t)
+            seqs[str(rid)] = (group, seq)
+            sched.add_seq_group(group)
+        if not sched.has_unfinished_seqs() and step > max(arrivals):
+            break
+        metas, outs = sched.schedule()
+        rec = {
+            "step": step,
+            "arrivals": [[int(r), list(map(int, toks))] for r, toks in arrivals.get(step, [])],
+            "prompt_run": bool(outs.prompt_run),
+            "scheduled": [m.request_id for m in metas],
+            "block_tables": {m.request_id: list(next(iter(m.block_tables.values()))) for m in metas},
+            "computed_block_nums": {m.request_id: list(m.computed_block_nums or []) for m in metas},
+            "blocks_to_nw": {str(k): [list(r) for r in v] for k, v in outs.blocks_to_nw.items()},
+            "blocks_to_copy": {str(k): list(v) for k, v in outs.blocks_to_copy.items()},
+            "waiting": [g.request_id for g in sched.waiting],
+            "running": [g.request_id for g in sched.running],
+            "free_gpu_blocks": sched.block_manager.get_num_free_gpu_blocks(),
+        }
+        if metas and outs.prompt_run:
+            toks, pos, meta, plens, sublens, *_ = runner._prepare_prompt(metas)
+            rec["inputs"] = {
+                "input_tokens": toks.tolist(), "input_positions": pos.tolist(),
+                "slot_mapping": meta.slot_mapping.tolist(), "prompt_lens": list(plens),
+                "subquery_lens": list(sublens), "max_seq_len": int(meta.max_seq_len),
+                "context_lens": meta.context_lens.tolist(), "block_tables": meta.block_tables.tolist(),
+                "start_loc": meta.start_loc.tolist(),
+            }
+        for m in metas:
+            sched.mark_blocks_as_computed(seqs[m.request_id][0])
+        finished = []
+        for m in metas:
+            group, seq = seqs[m.request_id]
+            tok = 7 + int(m.request_id) % 2           # two output streams: some continuations coincide
+            seq.append_token_id(tok, {tok: Logprob(0.0)})
+            if seq.get_output_len() >= lifetimes[int(m.request_id)]:
+                seq.status = SequenceStatus.FINISHED_STOPPED
+                sched.free_seq(seq)
+                finished.append(m.request_id)
+        sched.free_finished_seq_groups()
+        rec["finished"] = finished
+        steps.append(rec)
+    with open(os.path.join(OUT, f"scheduler_{name}.json"), "w") as f:
+        json.dump({"block_size": block_size, "num_gpu_blocks": num_gpu_blocks, "max_num_seqs": max_num_seqs,
+                   "max_num_batched_tokens": max_batched, "max_paddings": 256, "enable_prefix_caching": True,
+                   "lifetimes": {str(k): v for k, v in lifetimes.items()}, "steps": steps}, f)
+    print("scheduler", name, len(steps), "steps")
+
+
+def gen_prefix_caching():
+    prefix = list(range(500, 513))                      # 13 tokens: three full blocks of 4 and one token
+    other = list(range(900, 931))
+    arrivals = {
+        0: [(0, prefix + [1, 2, 3])],
+        2: [(1, prefix + [4, 5, 6, 7, 8])],             # shares the three computed blocks
+        3: [(2, prefix + [1, 2, 3])],                   # the same prompt as request 0, which still runs
+        6: [(3, other)],                                # unrelated
+        12: [(4, prefix + [9, 9])],                     # the sharers have finished: blocks come back from the evictor
+        16: [(5, list(range(2000, 2041)))],             # fills the pool: least recently used blocks are evicted
+        17: [(6, list(range(3000, 3030)))],
+        30: [(7, prefix + [1, 2, 3, 4])],               # after the eviction
+        31: [(8, other + [5])],
+    }
+    lifetimes = {0: 7, 1: 4, 2: 6, 3: 9, 4: 3, 5: 8, 6: 5, 7: 4, 8: 3}
+    _trace_prefix_scenario("prefix_caching", 4, 26, 8, 128, arrivals, lifetimes)
+
+
 def gen_utils():
     rng = random.Random(5)
     cases = []
@@ -295,8 +382,9 @@ def gen_utils():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    gen_paged_attention()
-    gen_prefill_attention()
-    gen_cache_layout()
-    gen_scheduler()
-    gen_utils()
+    only = set(sys.argv[1:])                 # e.g. `gen_golden.py prefix_caching`; nothing = everything
+    for tag, fn in (("paged_attention", gen_paged_attention), ("prefill_attention", gen_prefill_attention),
+                    ("cache_layout", gen_cache_layout), ("scheduler", gen_scheduler),
+                    ("prefix_caching", gen_prefix_caching), ("utils", gen_utils)):
+        if not only or tag in only:
+            fn()

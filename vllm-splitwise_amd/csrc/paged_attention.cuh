@@ -534,6 +534,41 @@ int launch_pa(const PaArgs& a) {
   return SW_OK;
 }
 
+}  // namespace sw
+#include "paged_attention_mfma.cuh"
+namespace sw {
+
+template <typename act_t, bool FP8, int HEAD, int BS>
+int launch_pa_mfma(const PaArgs& a, int qg) {
+  const int g = a.num_heads / a.num_kv_heads;
+  const int parts = a.partitioned ? (a.max_context_len + kPartitionSize - 1) / kPartitionSize : 1;
+  dim3 grid(a.num_kv_heads * (g / qg), a.num_seqs, parts);
+  const size_t smem = (size_t)kPaWaves * kPaMfmaHeads * kPaMfmaPRow * 2 + (size_t)kPaWaves * kPaMfmaHeads * HEAD * 4 +
+                      2 * kPaWaves * kPaMfmaHeads * 4;
+  paged_attention_mfma_kernel<act_t, FP8, HEAD, BS><<<grid, kPaThreads, smem, a.stream>>>(
+      a.partitioned ? a.tmp_out : a.out, a.exp_sums, a.max_logits, a.q, a.k, a.v, a.num_heads, a.num_kv_heads,
+      a.scale, a.block_tables, a.context_lens, a.max_num_blocks_per_seq, a.alibi, a.q_stride, a.kv_block_stride,
+      a.kv_head_stride, a.partitioned, qg);
+  SW_CHECK_LAUNCH();
+  if (a.partitioned) {
+    dim3 rgrid(a.num_heads, a.num_seqs);
+    paged_attention_reduce_kernel<act_t, HEAD><<<rgrid, 128, parts * sizeof(float), a.stream>>>(
+        a.out, a.exp_sums, a.max_logits, a.tmp_out, a.context_lens, parts);
+    SW_CHECK_LAUNCH();
+  }
+  return SW_OK;
+}
+
+// Query heads per workgroup of the matrix-core kernel: the largest divisor of the group size that
+// fits its 16 head columns; below 4 the vector kernels are the better fit (0 = do not use it).
+inline int pa_mfma_width(int group, int head_size, int block_size, int act_bytes, const void* q, int64_t q_stride) {
+  if (act_bytes != 2 || (head_size != 64 && head_size != 128) || (block_size != 16 && block_size != 32)) return 0;
+  if (reinterpret_cast<uintptr_t>(q) % 16 != 0 || q_stride % 8 != 0) return 0;     // 16-byte query fragments
+  int qg = group < kPaMfmaHeads ? group : kPaMfmaHeads;
+  while (group % qg) --qg;
+  return qg >= 4 ? qg : 0;
+}
+
 // Dispatch over head size / block size / query-group width for one (act, cache) pair.
 // Query-group widths above 1 are built for head sizes 64 and 128 and blocks of 16 / 32, up to
 // MAXQG query heads per workgroup: the widest width whose kernel still fits the register file
@@ -542,6 +577,17 @@ int launch_pa(const PaArgs& a) {
 template <typename act_t, bool FP8, int MAXQG>
 int dispatch_pa(const PaArgs& a) {
   const int g = a.num_heads / a.num_kv_heads;
+  if constexpr (!std::is_same<act_t, float>::value) {
+    const int qgm = pa_mfma_width(g, a.head_size, a.block_size, 2, a.q, a.q_stride);
+    if (qgm) {
+      if (a.head_size == 64) {
+        if (a.block_size == 16) return launch_pa_mfma<act_t, FP8, 64, 16>(a, qgm);
+        return launch_pa_mfma<act_t, FP8, 64, 32>(a, qgm);
+      }
+      if (a.block_size == 16) return launch_pa_mfma<act_t, FP8, 128, 16>(a, qgm);
+      return launch_pa_mfma<act_t, FP8, 128, 32>(a, qgm);
+    }
+  }
   int qg = 1;
   if (MAXQG > 1 && (a.head_size == 64 || a.head_size == 128) && a.block_size >= 16) {
     if (g % 8 == 0) qg = 8;

@@ -141,8 +141,9 @@ class CacheConfig:
             raise ValueError(f"GPU memory utilization must be less than 1.0. Got {gpu_memory_utilization}.")
         if cache_dtype not in ("auto", "fp8_e5m2"):
             raise ValueError(f"Unknown kv cache dtype: {cache_dtype}")
-        if enable_prefix_caching:
-            raise NotImplementedError("prefix caching is not built yet")
+        if enable_prefix_caching and cache_dtype != "auto":
+            # the prefix-aware prompt kernel reads the cached context in the activation dtype
+            raise NotImplementedError("prefix caching needs kv_cache_dtype 'auto'")
         self.num_gpu_blocks: Optional[int] = None
         self.num_cpu_blocks: Optional[int] = None
 

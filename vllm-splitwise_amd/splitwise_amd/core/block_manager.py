@@ -10,14 +10,22 @@ Behaviour restated from vllm/core/block_manager.py:13-487 with prefix caching of
   * a block shared by forked sequences is copied on the first append (copy-on-write);
   * watermark: a prompt is admitted only if 1% of the pool stays free afterwards.
 
-Blocks are plain integers with a reference count per pool; there are no per-block
-objects.  When a sequence is freed its blocks return to the pool in block-table order
+With prefix caching on (``enable_caching``) the pools are ``CachingBlockPool``s: full blocks are
+keyed by a hash of every token up to their end (vllm/sequence.py:188-197), a prompt whose leading
+blocks are already in the pool shares them, freed blocks stay findable until they are evicted, and
+eviction is least-recently-used with ties going to the block that hashes the most tokens
+(vllm/core/evictor.py:68-104); ``computed`` marks blocks whose KV has been written, so that a later
+prompt can skip them (block_manager.py:441-487).
+
+Blocks are plain integers with per-pool side tables; there are no per-block objects.  When a sequence is freed its blocks return to the pool in block-table order
 (the reference iterates a set of objects there, so its order depends on memory
 addresses and cannot be reproduced; block numbering is identical to the reference's
 until the first reuse of a freed block).
 """
 import enum
 from collections import deque
+from itertools import count, takewhile
+from os.path import commonprefix
 from typing import Deque, Dict, List, Optional, Tuple
 
 from ..sequence import Sequence, SequenceGroup, SequenceStatus
@@ -63,6 +71,95 @@ class BlockPool:
         return self.num_blocks - self._next_fresh + len(self._freed)
 
 
+class CachingBlockPool:
+    """Free-block accounting of one device with content-addressed blocks: BlockAllocator with
+    ``enable_caching=True`` (vllm/core/block_manager.py:13-113) over the LRU evictor
+    (vllm/core/evictor.py:53-119).  Same method names as ``BlockPool``; ``allocate`` takes the hash."""
+
+    def __init__(self, device: Device, block_size: int, num_blocks: int) -> None:
+        self.device = device
+        self.block_size = block_size
+        self.num_blocks = num_blocks
+        self.current_num_blocks = 0                    # blocks handed out at least once
+        self.cached_blocks: Dict[int, int] = {}        # hash -> block, blocks in use
+        self.free_table: Dict[int, int] = {}           # hash -> block, freed but not evicted (insertion order)
+        self._ref = [0] * num_blocks
+        self.block_hash: List[Optional[int]] = [None] * num_blocks
+        self.num_hashed_tokens = [0] * num_blocks
+        self.last_accessed = [-1.0] * num_blocks       # DEFAULT_LAST_ACCESSED_TIME, vllm/block.py:8
+        self.computed = [False] * num_blocks
+        self.default_hash_ctr = count()
+
+    def _evict(self) -> int:
+        """evictor.py:68-104: lowest last_accessed; among those the most hashed tokens; among those
+        the one freed first."""
+        if not self.free_table:
+            raise ValueError("No usable cache memory left")
+        best = None
+        for block in self.free_table.values():
+            if (best is None or self.last_accessed[block] < self.last_accessed[best]
+                    or (self.last_accessed[block] == self.last_accessed[best]
+                        and self.num_hashed_tokens[block] > self.num_hashed_tokens[best])):
+                best = block
+        del self.free_table[self.block_hash[best]]
+        self.computed[best] = False
+        return best
+
+    def _allocate_block(self, block_hash: int, num_hashed_tokens: int) -> int:
+        if self.current_num_blocks == self.num_blocks:
+            block = self._evict()
+        else:
+            block = self.current_num_blocks
+            self.current_num_blocks += 1
+        self.block_hash[block] = block_hash
+        self.num_hashed_tokens[block] = num_hashed_tokens
+        return block
+
+    def allocate(self, block_hash: Optional[int] = None, num_hashed_tokens: int = 0) -> int:
+        if block_hash is None:
+            block_hash = next(self.default_hash_ctr)
+        if block_hash in self.free_table:              # freed, not evicted yet: bring it back
+            assert block_hash not in self.cached_blocks
+            block = self.free_table.pop(block_hash)
+            assert self._ref[block] == 0
+            self.cached_blocks[block_hash] = block
+            self._ref[block] += 1
+            return block
+        if block_hash not in self.cached_blocks:
+            self.cached_blocks[block_hash] = self._allocate_block(block_hash, num_hashed_tokens)
+        block = self.cached_blocks[block_hash]
+        self._ref[block] += 1
+        return block
+
+    def share(self, block: int) -> None:
+        self._ref[block] += 1
+
+    def ref_count(self, block: int) -> int:
+        return self._ref[block]
+
+    def free(self, block: int) -> None:
+        if self._ref[block] == 0:
+            raise ValueError(f"Double free! block {block} on {self.device.name} is already freed.")
+        self._ref[block] -= 1
+        if self._ref[block] == 0:
+            h = self.block_hash[block]
+            assert h not in self.free_table
+            self.free_table[h] = block
+            del self.cached_blocks[h]
+
+    def get_num_free_blocks(self) -> int:
+        return self.num_blocks - self.current_num_blocks + len(self.free_table)
+
+    def contains_block(self, block_hash: int) -> bool:
+        return block_hash in self.cached_blocks or block_hash in self.free_table
+
+    def update_hash(self, block_hash: int, block: int) -> None:
+        assert not self.contains_block(block_hash)
+        del self.cached_blocks[self.block_hash[block]]
+        self.block_hash[block] = block_hash
+        self.cached_blocks[block_hash] = block
+
+
 class AllocStatus(enum.Enum):
     """vllm/core/block_manager.py:116-127."""
     OK = enum.auto()
@@ -73,8 +170,6 @@ class AllocStatus(enum.Enum):
 class BlockSpaceManager:
     def __init__(self, block_size: int, num_gpu_blocks: int, num_cpu_blocks: int, watermark: float = 0.01,
                  sliding_window: Optional[int] = None, enable_caching: bool = False) -> None:
-        if enable_caching:
-            raise NotImplementedError("prefix caching is not built yet")
         assert watermark >= 0.0
         self.block_size = block_size
         self.num_total_gpu_blocks = num_gpu_blocks
@@ -85,9 +180,10 @@ class BlockSpaceManager:
             self.block_sliding_window = sliding_window // block_size
         self.watermark = watermark
         self.watermark_blocks = int(watermark * num_gpu_blocks)
-        self.enable_caching = False
-        self.gpu_allocator = BlockPool(Device.GPU, block_size, num_gpu_blocks)
-        self.cpu_allocator = BlockPool(Device.CPU, block_size, num_cpu_blocks)
+        self.enable_caching = enable_caching
+        pool = CachingBlockPool if enable_caching else BlockPool
+        self.gpu_allocator = pool(Device.GPU, block_size, num_gpu_blocks)
+        self.cpu_allocator = pool(Device.CPU, block_size, num_cpu_blocks)
         self.block_tables: Dict[int, List[int]] = {}
         self._on_cpu: set = set()            # seq ids whose table holds CPU block numbers
 
@@ -110,6 +206,11 @@ class BlockSpaceManager:
         for logical in range(waiting[0].num_logical_blocks):
             if window is not None and logical >= window:
                 table.append(table[logical % window])
+            elif self.enable_caching:
+                # block_manager.py:199-201: every prompt block is addressed by the hash of the tokens up to
+                # its end -- the last, partly filled one too (over tokens it does not hold yet)
+                table.append(self.gpu_allocator.allocate(waiting[0].hash_of_block(logical),
+                                                         waiting[0].num_hashed_tokens_of_block(logical)))
             else:
                 table.append(self.gpu_allocator.allocate())
         # every waiting sequence of the group starts from the same prompt blocks; the
@@ -120,6 +221,30 @@ class BlockSpaceManager:
     # ------------------------------------------------------------------ appends
     def can_append_slot(self, seq_group: SequenceGroup) -> bool:
         return seq_group.num_seqs(status=SequenceStatus.RUNNING) <= self.gpu_allocator.get_num_free_blocks()
+
+    def _is_last_block_full(self, seq: Sequence) -> bool:
+        n = seq.get_len()
+        return n > 0 and n % self.block_size == 0
+
+    def _allocate_last_block(self, seq: Sequence) -> int:
+        """block_manager.py:254-267."""
+        if not self.enable_caching:
+            return self.gpu_allocator.allocate()
+        last = seq.num_logical_blocks - 1
+        block_hash = seq.hash_of_block(last) if self._is_last_block_full(seq) else None
+        return self.gpu_allocator.allocate(block_hash, seq.num_hashed_tokens_of_block(last))
+
+    def _maybe_promote_last_block(self, seq: Sequence, block: int) -> int:
+        """A block that has just become full gets its content hash, so that other sequences can share it;
+        if a block with that content exists already, that one is used instead (block_manager.py:218-252)."""
+        if not self.enable_caching or not self._is_last_block_full(seq):
+            return block
+        new_hash = seq.hash_of_block(seq.num_logical_blocks - 1)
+        if self.gpu_allocator.contains_block(new_hash):
+            self.gpu_allocator.free(block)
+            return self.gpu_allocator.allocate(new_hash)
+        self.gpu_allocator.update_hash(new_hash, block)
+        return block
 
     def append_slot(self, seq: Sequence) -> Optional[Tuple[int, int]]:
         """Makes room for the sequence's newest token; returns (src, dst) when the last block
@@ -132,12 +257,13 @@ class BlockSpaceManager:
             if window and len(table) >= window:
                 table.append(table[len(table) % window])
             else:
-                table.append(self.gpu_allocator.allocate())
+                table.append(self._allocate_last_block(seq))
                 return None
         last = table[-1]
         if self.gpu_allocator.ref_count(last) == 1:
+            table[-1] = self._maybe_promote_last_block(seq, last)
             return None
-        fresh = self.gpu_allocator.allocate()
+        fresh = self._allocate_last_block(seq)
         table[-1] = fresh
         self.gpu_allocator.free(last)
         return last, fresh
@@ -168,6 +294,8 @@ class BlockSpaceManager:
             for block in self.block_tables[seq.seq_id]:
                 if block in mapping:
                     dst.share(mapping[block])
+                elif self.enable_caching:
+                    mapping[block] = dst.allocate(src.block_hash[block], src.num_hashed_tokens[block])
                 else:
                     mapping[block] = dst.allocate()
                 new_table.append(mapping[block])
@@ -221,12 +349,47 @@ class BlockSpaceManager:
     def get_num_free_cpu_blocks(self) -> int:
         return self.cpu_allocator.get_num_free_blocks()
 
-    # prefix-caching hooks of the reference interface: no-ops with caching off
+    # ------------------------------------------------------------ prefix caching
     def access_all_blocks_in_seq(self, seq: Sequence, access_time: float) -> None:
-        pass
+        """block_manager.py:432-439 (the evictor's clock)."""
+        if not self.enable_caching:
+            return
+        stamps = self.gpu_allocator.last_accessed
+        for block in self.block_tables[seq.seq_id]:
+            stamps[block] = access_time
+
+    def compute_full_blocks_in_seq(self, seq: Sequence) -> None:
+        """block_manager.py:441-451, as written there: of the blocks that the sequence fills completely, all
+        but the last are marked, walking down until a marked one is met."""
+        table = self.block_tables.get(seq.seq_id)
+        if table is None:
+            return
+        max_full_block = seq.get_len() // self.block_size - 1
+        if max_full_block == -1:
+            return
+        computed = self.gpu_allocator.computed
+        for i in reversed(range(max_full_block)):
+            if computed[table[i]]:
+                break
+            computed[table[i]] = True
+
+    def get_all_computed_blocks(self, seq: Sequence) -> List[int]:
+        """Leading computed blocks, never the last block of the table (a prompt that is cached completely
+        would leave the model nothing to run, block_manager.py:453-464)."""
+        table = self.block_tables.get(seq.seq_id)
+        if table is None:
+            return []
+        computed = self.gpu_allocator.computed
+        return list(takewhile(lambda b: computed[b], table[:-1]))
 
     def get_common_computed_block_ids(self, seq_group: SequenceGroup) -> List[int]:
-        return []
+        if not self.enable_caching:
+            return []
+        ids_list = [self.get_all_computed_blocks(seq) for seq in seq_group.get_seqs()]
+        # (os.path.commonprefix of no lists is the empty STRING, which the reference passes on; a list here)
+        return list(commonprefix([ids for ids in ids_list if ids != []]))
 
     def mark_blocks_as_computed(self, seq_group: SequenceGroup) -> None:
-        pass
+        if self.enable_caching:
+            for seq in seq_group.get_seqs():
+                self.compute_full_blocks_in_seq(seq)

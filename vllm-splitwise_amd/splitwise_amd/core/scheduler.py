@@ -296,11 +296,17 @@ class Scheduler:
             for seq in group.get_seqs(status=SequenceStatus.RUNNING):
                 seq_data[seq.seq_id] = seq.data
                 block_tables[seq.seq_id] = self.block_manager.get_block_table(seq)
+                self.block_manager.access_all_blocks_in_seq(seq, now)     # the evictor's clock (scheduler.py:418)
             metas.append(SequenceGroupMetadata(
                 request_id=group.request_id, is_prompt=outputs.prompt_run, seq_data=seq_data,
                 sampling_params=group.sampling_params, block_tables=block_tables,
-                computed_block_nums=[], state=group.state))
+                # leading blocks whose KV is in the cache already: the prompt step skips them (scheduler.py:427-428)
+                computed_block_nums=self.block_manager.get_common_computed_block_ids(group), state=group.state))
         return metas
+
+    def mark_blocks_as_computed(self, seq_group: SequenceGroup) -> None:
+        """vllm/core/scheduler.py:543-544."""
+        self.block_manager.mark_blocks_as_computed(seq_group)
 
     def schedule(self) -> Tuple[List[SequenceGroupMetadata], SchedulerOutputs]:
         outputs = self._schedule()

@@ -128,6 +128,11 @@ class LLMEngine:
         now = time.monotonic()        # intervals (TTFT, TPOT, e2e) are taken against the monotonic arrival_time
         wall = time.time()
         scheduled = list(scheduler_outputs.scheduled_seq_groups) if groups is None else groups
+        if self.cache_config.enable_prefix_caching:
+            # the step has written the KV of every full block of these sequences: later prompts with the
+            # same leading tokens need not compute them again (llm_engine.py:543-547)
+            for group in scheduled:
+                self.scheduler.mark_blocks_as_computed(group)
         for group, out in zip(scheduled, output):
             seq = group.get_seqs(status=SequenceStatus.RUNNING)[0]
             sample = out.samples[0]
@@ -196,6 +201,10 @@ class LLMEngine:
             self.scheduler.free_seq(seq)
         self._free_later = []
         reported: List[SequenceGroup] = []
+        if self.cache_config.enable_prefix_caching:
+            for group, seq in pairs:
+                if not seq.is_finished() or seq.has_placeholder():
+                    self.scheduler.mark_blocks_as_computed(group)
         for (group, seq), out in zip(pairs, output):
             if not seq.has_placeholder():
                 continue        # ended (stop token, abort) before this step's token was accounted for: dropped

@@ -160,10 +160,17 @@ class Attention(nn.Module):
                     for sem_id, runs in input_metadata.blocks_to_nw.items():
                         for block_start, num_blocks in runs:
                             comm.put(sem_id, self.layer_id, block_start, num_blocks)
-            output = torch.empty_like(query)
-            _C.ops.prefill_attention(output, query, key, value, input_metadata.start_loc,
-                                     input_metadata.prompt_lens, input_metadata.max_seq_len, self.scale,
-                                     self.alibi_slopes, self.sliding_window)
+            tables = input_metadata.block_tables
+            if key_cache is not None and tables is not None and tables.numel() > 0:
+                # some prompt of the step continues a prefix that is in the cache already: the new tokens
+                # attend to the paged context and to each other (backends/xformers.py:166-177)
+                output = PagedAttentionImpl.forward_prefix(query, key, value, key_cache, value_cache, input_metadata,
+                                                           self.alibi_slopes)
+            else:
+                output = torch.empty_like(query)
+                _C.ops.prefill_attention(output, query, key, value, input_metadata.start_loc,
+                                         input_metadata.prompt_lens, input_metadata.max_seq_len, self.scale,
+                                         self.alibi_slopes, self.sliding_window)
         else:
             output = PagedAttentionImpl.forward_decode(query, key_cache, value_cache, input_metadata,
                                                        self.num_kv_heads, self.scale, self.alibi_slopes)

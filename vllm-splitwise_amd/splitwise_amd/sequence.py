@@ -109,6 +109,14 @@ class Sequence:
         """Blocks spanned by the tokens seen so far (len(logical_token_blocks) in the reference)."""
         return -(-self.data.get_len() // self.block_size)
 
+    def hash_of_block(self, logical_idx: int) -> int:
+        """Content address of a block for prefix caching: every token from the start of the sequence to
+        the block's end (vllm/sequence.py:188-194; the second member is the reference's lora_int_id)."""
+        return hash((tuple(self.data.get_token_ids()[0:self.num_hashed_tokens_of_block(logical_idx)]), 0))
+
+    def num_hashed_tokens_of_block(self, logical_idx: int) -> int:
+        return logical_idx * self.block_size + self.block_size
+
     def append_token_id(self, token_id: int, logprobs: Dict[int, Logprob]) -> None:
         assert token_id in logprobs
         self.output_logprobs.append(logprobs)

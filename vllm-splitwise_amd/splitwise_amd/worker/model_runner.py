@@ -93,7 +93,9 @@ class ModelRunner:
 
     # ----------------------------------------------------------------- prompts
     def _prompt_rows(self, metas: List[SequenceGroupMetadata]):
-        """Per prompt: (tokens, positions, slots)."""
+        """Per prompt: (new tokens, their positions, their slots, tokens already cached, blocks of those).
+        Leading blocks that the block manager reports as computed are skipped: only the rest of the prompt
+        is run, against the cached context (model_runner.py:153-168; prefix caching)."""
         rows = []
         for meta in metas:
             assert meta.is_prompt
@@ -102,6 +104,10 @@ class ModelRunner:
             seq_id = seq_ids[0]
             tokens = meta.seq_data[seq_id].get_token_ids()
             n = len(tokens)
+            computed, prefix = 0, []
+            if meta.computed_block_nums and self.sliding_window is None and meta.block_tables is not None:
+                prefix = list(meta.computed_block_nums)
+                computed = len(prefix) * self.block_size
             if meta.block_tables is None:              # profiling run: nothing is cached
                 slots = [_PAD_SLOT_ID] * n
             else:
@@ -109,54 +115,68 @@ class ModelRunner:
                 bs = self.block_size
                 # with a sliding window only the last `window` tokens are kept (model_runner.py:195-209)
                 start = 0 if self.sliding_window is None else max(0, n - self.sliding_window)
-                slots = [_PAD_SLOT_ID if i < start else table[i // bs] * bs + i % bs for i in range(n)]
-            rows.append((tokens, list(range(n)), slots))
+                slots = [_PAD_SLOT_ID if i < start else table[i // bs] * bs + i % bs for i in range(computed, n)]
+            rows.append((tokens[computed:], list(range(computed, n)), slots, computed, prefix))
         return rows
+
+    def _prefix_tensors(self, rows):
+        """(cached lengths, block tables of the cached prefixes) as the prompt kernels take them; the table
+        has no columns when no prompt of the step has a cached prefix (model_runner.py:236-249)."""
+        context_lens = self._to_device(np.asarray([r[3] for r in rows], dtype=np.int32), torch.int32)
+        width = max(len(r[4]) for r in rows)
+        if width == 0:
+            return context_lens, torch.empty((len(rows), 0), dtype=torch.int32, device=self.device)
+        return context_lens, self._to_device(_pad_2d([r[4] for r in rows], width, 0, np.int32), torch.int32)
 
     def _prepare_prompt(self, metas: List[SequenceGroupMetadata]):
         """Padded layout, identical to the reference's tensors (model_runner.py:126-272).
         -> (input_tokens [B, L], input_positions [B, L], InputMetadata, prompt_lens, subquery_lens)"""
         assert len(metas) > 0
         rows = self._prompt_rows(metas)
-        prompt_lens = [len(r[0]) for r in rows]
-        max_len = max(prompt_lens)
+        subquery_lens = [len(r[0]) for r in rows]
+        prompt_lens = [r[3] + len(r[0]) for r in rows]
+        max_len = max(subquery_lens)
         assert max_len > 0
         tokens = self._to_device(_pad_2d([r[0] for r in rows], max_len, 0, np.int64), torch.long)
         positions = self._to_device(_pad_2d([r[1] for r in rows], max_len, 0, np.int64), torch.long)
         slots = self._to_device(_pad_2d([r[2] for r in rows], max_len, _PAD_SLOT_ID, np.int64), torch.long)
         start_loc = self._to_device(np.arange(0, len(rows) * max_len, max_len, dtype=np.int32), torch.int32)
+        context_lens, block_tables = self._prefix_tensors(rows)
         md = InputMetadata(
             is_prompt=True, slot_mapping=slots,
             prompt_lens=self._to_device(np.asarray(prompt_lens, dtype=np.int32), torch.int32),
             max_seq_len=max_len, start_loc=start_loc, max_context_len=None,
-            context_lens=self._to_device(np.zeros(len(rows), dtype=np.int32), torch.int32),
-            block_tables=torch.empty((len(rows), 0), dtype=torch.int32, device=self.device),
+            context_lens=context_lens, block_tables=block_tables,
             use_cuda_graph=False, kv_cache_dtype=self.kv_cache_dtype)
-        return tokens, positions, md, prompt_lens, list(prompt_lens)
+        return tokens, positions, md, prompt_lens, subquery_lens
 
     def _prepare_prompt_packed(self, metas: List[SequenceGroupMetadata]):
-        """-> (input_tokens [T], input_positions [T], InputMetadata, prompt_lens, row starts)."""
+        """-> (input_tokens [T], input_positions [T], InputMetadata, subquery_lens, row starts)."""
         rows = self._prompt_rows(metas)
-        prompt_lens = [len(r[0]) for r in rows]
+        subquery_lens = [len(r[0]) for r in rows]
+        prompt_lens = [r[3] + len(r[0]) for r in rows]
         starts, total = [], 0
-        for n in prompt_lens:
+        for n in subquery_lens:
             starts.append(total)
             total += -(-n // _PROMPT_ROW_ALIGN) * _PROMPT_ROW_ALIGN
         tokens = np.zeros(total, dtype=np.int64)
         positions = np.zeros(total, dtype=np.int64)
         slots = np.full(total, _PAD_SLOT_ID, dtype=np.int64)
-        for (tok, pos, slot), s in zip(rows, starts):
+        for (tok, pos, slot, _, _), s in zip(rows, starts):
             n = len(tok)
             tokens[s:s + n] = tok
             positions[s:s + n] = pos
             slots[s:s + n] = slot
+        context_lens = block_tables = None
+        if any(r[3] for r in rows):
+            context_lens, block_tables = self._prefix_tensors(rows)
         md = InputMetadata(
             is_prompt=True, slot_mapping=self._to_device(slots, torch.long),
             prompt_lens=self._to_device(np.asarray(prompt_lens, dtype=np.int32), torch.int32),
-            max_seq_len=max(prompt_lens), start_loc=self._to_device(np.asarray(starts, dtype=np.int32), torch.int32),
-            max_context_len=None, context_lens=None, block_tables=None, use_cuda_graph=False,
+            max_seq_len=max(subquery_lens), start_loc=self._to_device(np.asarray(starts, dtype=np.int32), torch.int32),
+            max_context_len=None, context_lens=context_lens, block_tables=block_tables, use_cuda_graph=False,
             kv_cache_dtype=self.kv_cache_dtype)
-        return (self._to_device(tokens, torch.long), self._to_device(positions, torch.long), md, prompt_lens,
+        return (self._to_device(tokens, torch.long), self._to_device(positions, torch.long), md, subquery_lens,
                 starts)
 
     # ------------------------------------------------------------------ decode
@@ -271,7 +291,7 @@ class ModelRunner:
                 tokens, positions, md, prompt_lens, starts = self._prepare_prompt_packed(metas)
                 last_rows = [s + n - 1 for s, n in zip(starts, prompt_lens)]
             else:
-                tokens, positions, md, prompt_lens, _ = self._prepare_prompt(metas)
+                tokens, positions, md, _, prompt_lens = self._prepare_prompt(metas)     # rows = the new tokens
                 width = tokens.shape[1]
                 last_rows = [i * width + n - 1 for i, n in enumerate(prompt_lens)]
             sampling_md = self._prepare_sample(metas, last_rows)
