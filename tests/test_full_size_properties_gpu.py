@@ -87,11 +87,12 @@ def test_decode_attention_properties_at_the_70b_tp4_shape(num_seqs, hi, kv_cache
     moved = run_kernel("v1", q, kc[perm], vc[perm], kv_heads, scale, inv[tables.long()].to(torch.int32), lens, BS, None,
                        kv_cache)
     assert torch.equal(moved, v1)
-    # a sequence on its own equals the same sequence inside the batch
+    # a sequence on its own equals the same sequence inside the batch (a launch of few workgroups spreads a
+    # sequence over more waves, so the fp32 partial sums meet in another order: equal to the last bit or two)
     pick = num_seqs // 3
     one = run_kernel("v1", q[pick:pick + 1], kc, vc, kv_heads, scale, tables[pick:pick + 1], lens[pick:pick + 1], BS,
                      None, kv_cache)
-    assert torch.equal(one[0], v1[pick])
+    torch.testing.assert_close(one[0].float(), v1[pick].float(), atol=1e-4, rtol=1.6e-2)
     # and that sequence against the CPU oracle (gathering its blocks only)
     nblk = -(-int(lens[pick]) // BS)
     blocks = tables[pick, :nblk].long()

@@ -538,18 +538,37 @@ int launch_pa(const PaArgs& a) {
 #include "paged_attention_mfma.cuh"
 namespace sw {
 
+template <typename act_t, bool FP8, int HEAD, int BS, int NW>
+int launch_pa_mfma_nw(const PaArgs& a, int qg, dim3 grid) {
+  const size_t smem = (size_t)NW * kPaMfmaHeads * kPaMfmaPRow * 2 + (size_t)NW * qg * HEAD * 4 + 2 * NW * qg * 4;
+  auto kernel = paged_attention_mfma_kernel<act_t, FP8, HEAD, BS, NW>;
+  if (smem > 64 * 1024) {
+    static bool raised = false;             // per instantiation: the attribute sticks to the function
+    if (!raised) {
+      SW_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+      raised = true;
+    }
+  }
+  kernel<<<grid, NW * 64, smem, a.stream>>>(
+      a.partitioned ? a.tmp_out : a.out, a.exp_sums, a.max_logits, a.q, a.k, a.v, a.num_heads, a.num_kv_heads,
+      a.scale, a.block_tables, a.context_lens, a.max_num_blocks_per_seq, a.alibi, a.q_stride, a.kv_block_stride,
+      a.kv_head_stride, a.partitioned, qg);
+  SW_CHECK_LAUNCH();
+  return SW_OK;
+}
+
 template <typename act_t, bool FP8, int HEAD, int BS>
 int launch_pa_mfma(const PaArgs& a, int qg) {
   const int g = a.num_heads / a.num_kv_heads;
   const int parts = a.partitioned ? (a.max_context_len + kPartitionSize - 1) / kPartitionSize : 1;
   dim3 grid(a.num_kv_heads * (g / qg), a.num_seqs, parts);
-  const size_t smem = (size_t)kPaWaves * kPaMfmaHeads * kPaMfmaPRow * 2 + (size_t)kPaWaves * kPaMfmaHeads * HEAD * 4 +
-                      2 * kPaWaves * kPaMfmaHeads * 4;
-  paged_attention_mfma_kernel<act_t, FP8, HEAD, BS><<<grid, kPaThreads, smem, a.stream>>>(
-      a.partitioned ? a.tmp_out : a.out, a.exp_sums, a.max_logits, a.q, a.k, a.v, a.num_heads, a.num_kv_heads,
-      a.scale, a.block_tables, a.context_lens, a.max_num_blocks_per_seq, a.alibi, a.q_stride, a.kv_block_stride,
-      a.kv_head_stride, a.partitioned, qg);
-  SW_CHECK_LAUNCH();
+  // every SIMD of the 256 compute units wants a wave: a launch of few workgroups takes 8 waves each
+  // (16 would leave a wave 128 registers, which this kernel's fragments do not fit)
+  const int64_t wgs = (int64_t)grid.x * grid.y * grid.z;
+  const int rc = wgs >= 256 ? launch_pa_mfma_nw<act_t, FP8, HEAD, BS, 4>(a, qg, grid)
+                            : launch_pa_mfma_nw<act_t, FP8, HEAD, BS, 8>(a, qg, grid);
+  if (rc != SW_OK) return rc;
   if (a.partitioned) {
     dim3 rgrid(a.num_heads, a.num_seqs);
     paged_attention_reduce_kernel<act_t, HEAD><<<rgrid, 128, parts * sizeof(float), a.stream>>>(
@@ -561,12 +580,13 @@ int launch_pa_mfma(const PaArgs& a, int qg) {
 
 // Query heads per workgroup of the matrix-core kernel: the largest divisor of the group size that
 // fits its 16 head columns; below 4 the vector kernels are the better fit (0 = do not use it).
-inline int pa_mfma_width(int group, int head_size, int block_size, int act_bytes, const void* q, int64_t q_stride) {
+inline int pa_mfma_width(int group, int head_size, int block_size, int act_bytes, const void* q, int64_t q_stride,
+                         int min_width = 4) {
   if (act_bytes != 2 || (head_size != 64 && head_size != 128) || (block_size != 16 && block_size != 32)) return 0;
   if (reinterpret_cast<uintptr_t>(q) % 16 != 0 || q_stride % 8 != 0) return 0;     // 16-byte query fragments
   int qg = group < kPaMfmaHeads ? group : kPaMfmaHeads;
   while (group % qg) --qg;
-  return qg >= 4 ? qg : 0;
+  return qg >= min_width ? qg : 0;
 }
 
 // Dispatch over head size / block size / query-group width for one (act, cache) pair.
@@ -578,7 +598,10 @@ template <typename act_t, bool FP8, int MAXQG>
 int dispatch_pa(const PaArgs& a) {
   const int g = a.num_heads / a.num_kv_heads;
   if constexpr (!std::is_same<act_t, float>::value) {
-    const int qgm = pa_mfma_width(g, a.head_size, a.block_size, 2, a.q, a.q_stride);
+    // bf16 activations over an fp8 cache have no packed vector path (e5m2 widens to f16, not bf16, by a byte
+    // move): the matrix-core kernel, which re-expresses q and p in f16, takes them whatever the group size
+    constexpr bool kNoPackedPath = FP8 && std::is_same<act_t, bf16_t>::value;
+    const int qgm = pa_mfma_width(g, a.head_size, a.block_size, 2, a.q, a.q_stride, kNoPackedPath ? 1 : 4);
     if (qgm) {
       if (a.head_size == 64) {
         if (a.block_size == 16) return launch_pa_mfma<act_t, FP8, 64, 16>(a, qgm);

@@ -59,8 +59,11 @@ __device__ __forceinline__ pa_u32x4 e5m2x8_to_f16x8(uint32_t lo, uint32_t hi) {
 constexpr int kPaMfmaHeads = 16;        // head columns of one workgroup
 constexpr int kPaMfmaPRow = 72;         // 16-bit elements per row of the probability strip (64 + padding)
 
-template <typename act_t, bool FP8, int HEAD, int BS>
-__global__ void __launch_bounds__(kPaThreads)
+// NW waves per workgroup share one (sequence, head group[, partition]): 64-token groups go to the waves
+// round robin.  A launch of few workgroups takes more waves each, so that every SIMD of the chip
+// still has a wave streaming (the launcher picks 4 or 8).
+template <typename act_t, bool FP8, int HEAD, int BS, int NW>
+__global__ void __launch_bounds__(NW * 64)
 paged_attention_mfma_kernel(void* __restrict__ out_, float* __restrict__ exp_sums, float* __restrict__ max_logits,
                             const void* __restrict__ q_, const void* __restrict__ k_cache_,
                             const void* __restrict__ v_cache_, int num_heads, int num_kv_heads, float scale,
@@ -77,10 +80,10 @@ paged_attention_mfma_kernel(void* __restrict__ out_, float* __restrict__ exp_sum
   static_assert(HEAD % 32 == 0 && (BS == 16 || BS == 32), "head size / block size of the matrix-core decode kernel");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  S* p_s = reinterpret_cast<S*>(smem);                                            // [4][16][kPaMfmaPRow]
-  float* acc_s = reinterpret_cast<float*>(smem + kPaWaves * kPaMfmaHeads * kPaMfmaPRow * 2);   // [4][16][HEAD]
-  float* m_s = acc_s + kPaWaves * kPaMfmaHeads * HEAD;                            // [4][16]
-  float* l_s = m_s + kPaWaves * kPaMfmaHeads;                                     // [4][16]
+  S* p_s = reinterpret_cast<S*>(smem);                                            // [NW][16][kPaMfmaPRow]
+  float* acc_s = reinterpret_cast<float*>(smem + NW * kPaMfmaHeads * kPaMfmaPRow * 2);   // [NW][qg][HEAD]
+  float* m_s = acc_s + NW * qg * HEAD;                                            // [NW][qg]
+  float* l_s = m_s + NW * qg;                                                     // [NW][qg]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -145,7 +148,7 @@ paged_attention_mfma_kernel(void* __restrict__ out_, float* __restrict__ exp_sum
   S* p_w = p_s + wave * kPaMfmaHeads * kPaMfmaPRow;
   const int n_groups = (tok_end - tok_begin + 63) >> 6;
 
-  for (int g = wave; g < n_groups; g += kPaWaves) {
+  for (int g = wave; g < n_groups; g += NW) {
     const int g_tok0 = tok_begin + (g << 6);
 
     // ------------------------------------------------ loads: 4 key tiles, 2 x DT value fragments
@@ -260,27 +263,29 @@ paged_attention_mfma_kernel(void* __restrict__ out_, float* __restrict__ exp_sum
   // ------------------------------------------------ merge the four waves
   l_lane += __shfl_xor(l_lane, 16, 64);
   l_lane += __shfl_xor(l_lane, 32, 64);
-  if (kq == 0) {
-    m_s[wave * kPaMfmaHeads + r] = m_run;
-    l_s[wave * kPaMfmaHeads + r] = l_lane;
-  }
+  if (r < qg) {
+    if (kq == 0) {
+      m_s[wave * qg + r] = m_run;
+      l_s[wave * qg + r] = l_lane;
+    }
 #pragma unroll
-  for (int dt = 0; dt < DT; ++dt)
-    *reinterpret_cast<pa_f32x4*>(acc_s + (wave * kPaMfmaHeads + r) * HEAD + 16 * dt + 4 * kq) = acc[dt];
+    for (int dt = 0; dt < DT; ++dt)
+      *reinterpret_cast<pa_f32x4*>(acc_s + (wave * qg + r) * HEAD + 16 * dt + 4 * kq) = acc[dt];
+  }
   __syncthreads();
 
-  for (int i = tid; i < qg * HEAD; i += kPaThreads) {
+  for (int i = tid; i < qg * HEAD; i += NW * 64) {
     const int h = i / HEAD;
     const int d = i - h * HEAD;
     float m = -FLT_MAX;
 #pragma unroll
-    for (int w = 0; w < kPaWaves; ++w) m = fmaxf(m, m_s[w * kPaMfmaHeads + h]);
+    for (int w = 0; w < NW; ++w) m = fmaxf(m, m_s[w * qg + h]);
     float l = 0.f, o = 0.f;
 #pragma unroll
-    for (int w = 0; w < kPaWaves; ++w) {
-      const float f = __expf(m_s[w * kPaMfmaHeads + h] - m);
-      l = fmaf(l_s[w * kPaMfmaHeads + h], f, l);
-      o = fmaf(acc_s[(w * kPaMfmaHeads + h) * HEAD + d], f, o);
+    for (int w = 0; w < NW; ++w) {
+      const float f = __expf(m_s[w * qg + h] - m);
+      l = fmaf(l_s[w * qg + h], f, l);
+      o = fmaf(acc_s[(w * qg + h) * HEAD + d], f, o);
     }
     const float res = o * __fdividef(1.f, l + 1e-6f);
     const int head = head0 + h;

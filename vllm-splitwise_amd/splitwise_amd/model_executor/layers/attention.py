@@ -37,13 +37,21 @@ class PagedAttentionImpl:
     @staticmethod
     def query_group_width(num_heads: int, num_kv_heads: int, head_size: int, block_size: int,
                           dtype: torch.dtype, kv_cache_dtype: str) -> int:
-        """Query heads one workgroup of the decode kernel serves from a single pass over K and V
-        (the dispatch rule of csrc/paged_attention.cuh: powers of two up to 8 for f16 and bf16,
-        2 for bf16 over an fp8 cache, 1 for fp32; head sizes 64 / 128 and blocks of 16 / 32 only)."""
+        """Query heads one workgroup of the decode kernel serves from a single pass over K and V (the
+        dispatch rule of csrc/paged_attention.cuh).  f16 / bf16, head sizes 64 / 128, blocks of 16 / 32:
+        groups with a divisor of 4 or more go to the matrix-core kernel, which takes the largest divisor
+        up to 16; smaller groups to the vector kernels (2 heads for an even group; 1 for fp32)."""
         if head_size not in (64, 128) or block_size < 16:
             return 1
-        cap = {torch.float16: 8, torch.bfloat16: 2 if kv_cache_dtype == "fp8_e5m2" else 8}.get(dtype, 1)
         group = num_heads // num_kv_heads
+        if dtype in (torch.float16, torch.bfloat16) and block_size in (16, 32):
+            width = min(group, 16)
+            while group % width:
+                width -= 1
+            # (bf16 over an fp8 cache has no packed vector path: the matrix-core kernel takes every group size)
+            if width >= 4 or (dtype == torch.bfloat16 and kv_cache_dtype == "fp8_e5m2"):
+                return width
+        cap = {torch.float16: 8, torch.bfloat16: 8}.get(dtype, 1)
         width = 8 if group % 8 == 0 else 4 if group % 4 == 0 else 2 if group % 2 == 0 else 1
         return min(width, cap)
 
@@ -60,9 +68,9 @@ class PagedAttentionImpl:
             return True
         workgroups = num_seqs * num_heads // max(query_group, 1)
         if query_group >= 4:
-            # a workgroup that serves 4 or 8 query heads is dot-product bound and long-running:
-            # partitions pay until the launch fills every compute unit twice over
-            return workgroups >= 512
+            # the matrix-core kernel (8 waves per workgroup below 256 workgroups): unpartitioned from 128
+            # workgroups, and for short contexts whatever the launch size
+            return workgroups >= 128 or max_context_len <= 2 * _PARTITION_SIZE
         if workgroups >= 512:
             return True
         if workgroups >= 256:
