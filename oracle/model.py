@@ -74,7 +74,7 @@ def llama_logits(sd: Dict[str, torch.Tensor], cfg: dict, tokens: List[int], prom
         g, u = gu.chunk(2, -1)
         x = x + (F.silu(g) * u) @ sd[p + "mlp.down_proj.weight"].t()
     x = _rms(x, sd["norm.weight"], eps)
-    return x @ sd["lm_head_weight"].t()
+    return x @ sd["lm_head.weight"].t()
 
 
 def opt_logits(sd: Dict[str, torch.Tensor], cfg: dict, tokens: List[int]) -> torch.Tensor:

@@ -75,3 +75,61 @@ def test_a_worker_that_dies_in_the_handshake_fails_the_set_up_at_once(monkeypatc
         from splitwise_amd.model_executor import parallel_state
         parallel_state.destroy_model_parallel()
         dist.destroy_process_group()
+
+
+def _vocab_rank(rank: int, init_method: str, queue) -> None:
+    """One rank of a 4-way vocabulary-parallel embedding + output head on gloo (CPU tensors)."""
+    try:
+        import torch
+        import torch.distributed as dist
+        from splitwise_amd.model_executor import parallel_state
+        from splitwise_amd.model_executor.layers.vocab_parallel_embedding import ParallelLMHead, VocabParallelEmbedding
+        from splitwise_amd.model_executor.layers.sampler import Sampler
+        dist.init_process_group("gloo", rank=rank, world_size=4, init_method=init_method)
+        parallel_state.initialize_model_parallel(4)
+        vocab, hidden = 1000, 32                              # padded to 1024: 256 rows per rank, 24 of them padding
+        g = torch.Generator().manual_seed(0)
+        table = torch.randn(vocab, hidden, generator=g)
+        head = torch.randn(vocab, hidden, generator=g)
+        emb = VocabParallelEmbedding(vocab, hidden, torch.float32)
+        emb.weight_loader(emb.weight, table)
+        lm = ParallelLMHead(vocab, hidden, torch.float32)
+        lm.weight_loader(lm.weight, head)
+        assert emb.weight.shape == (256, hidden) and emb.num_embeddings_padded == 1024
+        ids = torch.tensor([0, 255, 256, 511, 767, 768, 999, 3])
+        out = emb(ids)
+        ok = torch.allclose(out, table[ids], atol=0, rtol=0)
+        hid = torch.randn(5, hidden, generator=g)
+        logits = Sampler(vocab)._get_logits(hid, lm.weight, None)
+        if rank == 0:
+            ok = ok and logits.shape == (5, vocab) and torch.allclose(logits, hid @ head.t(), atol=1e-5, rtol=1e-5)
+        else:
+            ok = ok and logits is None
+        dist.barrier()
+        dist.destroy_process_group()
+        queue.put((rank, "ok" if ok else "wrong values"))
+    except BaseException:                         # noqa: BLE001
+        import traceback
+        queue.put((rank, traceback.format_exc()))
+
+
+def test_vocabulary_parallel_embedding_and_head_over_four_ranks():
+    """vllm/model_executor/layers/vocab_parallel_embedding.py:98-111 and layers/sampler.py:44-57: the lookup is
+    exact (each token's row lives on one rank, the others add zeros) and the gathered logits are those of
+    the full head, on the pool's first rank only."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    queue = ctx.Queue()
+    with tempfile.TemporaryDirectory() as tmp:
+        init = "file://" + os.path.join(tmp, "rendezvous")
+        procs = [ctx.Process(target=_vocab_rank, args=(r, init, queue), daemon=True) for r in range(4)]
+        for p in procs:
+            p.start()
+        try:
+            results = dict(queue.get(timeout=120) for _ in range(4))
+        finally:
+            for p in procs:
+                p.join(timeout=10)
+                if p.is_alive():
+                    p.kill()
+    assert results == {0: "ok", 1: "ok", 2: "ok", 3: "ok"}, results

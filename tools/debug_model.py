@@ -16,7 +16,7 @@ meta = [SequenceGroupMetadata("0", True, {0: SequenceData(toks)}, SamplingParams
 t, p, md, pl, st = w.model_runner._prepare_prompt_packed(meta)
 with torch.inference_mode():
     hid = m(t.view(-1), p.view(-1), w.gpu_cache, md)
-    logits = (hid[:5].float() @ m.lm_head_weight.float().t()).cpu()
+    logits = (hid[:5].float() @ m.lm_head.weight.float().t()).cpu()
 ref = omodel.llama_logits(sd, cfg, toks)
 print("max diff logits", (logits - ref).abs().max().item(), "ref absmax", ref.abs().max().item())
 # op-level checks

@@ -107,9 +107,13 @@ class Sampler(nn.Module):
         logits = torch.matmul(hidden_states, embedding.t())
         if embedding_bias is not None:
             logits += embedding_bias
-        # the embedding and the output head are replicated on every tensor-parallel rank (the
-        # reference shards them over the vocabulary and gathers here, sampler.py:44-57)
-        return logits[:, :self.org_vocab_size]
+        # the output head is sharded over the vocabulary: every rank has the logits of its range, the
+        # pool's first rank (the one that samples and reports) gets them all (sampler.py:44-57)
+        from ..parallel_state import tensor_model_parallel_gather
+        logits = tensor_model_parallel_gather(logits, dst=0)
+        if logits is not None:
+            logits = logits[:, :self.org_vocab_size]           # drop the padding of the sharded vocabulary
+        return logits
 
     def forward(self, embedding: torch.Tensor, hidden_states: torch.Tensor,
                 sampling_metadata: SamplingMetadata,
@@ -117,8 +121,8 @@ class Sampler(nn.Module):
         hidden_states = hidden_states.reshape(-1, hidden_states.shape[-1])
         hidden_states = hidden_states.index_select(0, sampling_metadata.selected_token_indices)
         logits = self._get_logits(hidden_states, embedding, embedding_bias)
-        if not sampling_metadata.perform_sampling:
-            return None
+        if logits is None or not sampling_metadata.perform_sampling:
+            return None                                        # a tensor-parallel follower: rank 0 samples
         return self.sample_from_logits(logits, sampling_metadata)
 
     @staticmethod

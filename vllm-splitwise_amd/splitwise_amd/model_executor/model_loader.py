@@ -59,10 +59,9 @@ def _random_full(name: str, shape, dtype: torch.dtype, device: torch.device, see
 
 @torch.no_grad()
 def _random_init(model: nn.Module, seed: int) -> None:
-    from .layers.linear import _LinearBase
     owner = {}
     for mod_name, mod in model.named_modules():
-        if isinstance(mod, _LinearBase):
+        if hasattr(mod, "weight_loader") and hasattr(mod, "full_shape"):     # sharded layers place their own slice
             for pname, p in mod._parameters.items():
                 if p is not None:
                     owner[id(p)] = mod

@@ -15,6 +15,7 @@ from ..layers.attention import Attention
 from ..layers.basic import RMSNorm, RotaryEmbedding, SiluAndMul
 from ..layers.linear import (LinearMethodBase, MergedColumnParallelLinear, QKVParallelLinear, RowParallelLinear)
 from ..layers.sampler import Sampler, SamplingMetadata
+from ..layers.vocab_parallel_embedding import ParallelLMHead, VocabParallelEmbedding
 from ..parallel_state import get_tensor_model_parallel_world_size
 
 KVCache = Tuple[Optional[torch.Tensor], Optional[torch.Tensor]]
@@ -83,12 +84,11 @@ class LlamaForCausalLM(nn.Module):
     def __init__(self, cfg: dict, dtype: torch.dtype, linear_method: Optional[LinearMethodBase] = None) -> None:
         super().__init__()
         self.config = cfg
-        self.embed_tokens = nn.Embedding(cfg["vocab_size"], cfg["hidden_size"], dtype=dtype)
+        self.embed_tokens = VocabParallelEmbedding(cfg["vocab_size"], cfg["hidden_size"], dtype)
         self.layers = nn.ModuleList([LlamaDecoderLayer(cfg, dtype, linear_method)
                                      for _ in range(cfg["num_hidden_layers"])])
         self.norm = RMSNorm(cfg["hidden_size"], cfg.get("rms_norm_eps", 1e-6))
-        self.lm_head_weight = nn.Parameter(torch.empty(cfg["vocab_size"], cfg["hidden_size"], dtype=dtype),
-                                           requires_grad=False)
+        self.lm_head = ParallelLMHead(cfg["vocab_size"], cfg["hidden_size"], dtype)
         self.sampler = Sampler(cfg["vocab_size"])
 
     def forward(self, input_ids, positions, kv_caches: List[KVCache], input_metadata: InputMetadata):
@@ -100,4 +100,4 @@ class LlamaForCausalLM(nn.Module):
         return hidden_states
 
     def sample(self, hidden_states, sampling_metadata: SamplingMetadata):
-        return self.sampler(self.lm_head_weight, hidden_states, sampling_metadata)
+        return self.sampler(self.lm_head.weight, hidden_states, sampling_metadata)

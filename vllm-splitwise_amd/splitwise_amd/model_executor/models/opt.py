@@ -14,6 +14,7 @@ from ..input_metadata import InputMetadata
 from ..layers.attention import Attention
 from ..layers.linear import ColumnParallelLinear, LinearMethodBase, QKVParallelLinear, RowParallelLinear
 from ..layers.sampler import Sampler, SamplingMetadata
+from ..layers.vocab_parallel_embedding import VocabParallelEmbedding
 from ..parallel_state import get_tensor_model_parallel_world_size
 
 KVCache = Tuple[Optional[torch.Tensor], Optional[torch.Tensor]]
@@ -60,7 +61,7 @@ class OPTForCausalLM(nn.Module):
         super().__init__()
         self.config = cfg
         hidden = cfg["hidden_size"]
-        self.embed_tokens = nn.Embedding(cfg["vocab_size"], hidden, dtype=dtype)
+        self.embed_tokens = VocabParallelEmbedding(cfg["vocab_size"], hidden, dtype)
         self.embed_positions = nn.Embedding(cfg["max_position_embeddings"] + self.POSITION_OFFSET, hidden,
                                             dtype=dtype)
         self.layers = nn.ModuleList([OPTDecoderLayer(cfg, dtype, linear_method)

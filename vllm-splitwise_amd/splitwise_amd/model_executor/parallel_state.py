@@ -102,3 +102,20 @@ def tensor_model_parallel_all_gather(x: torch.Tensor, dim: int = -1) -> torch.Te
     parts = [torch.empty_like(src) for _ in range(_TP_WORLD)]
     dist.all_gather(parts, src, group=_TP_GROUP)
     return torch.cat(parts, dim=dim).to(x.device)
+
+
+def tensor_model_parallel_gather(x: torch.Tensor, dst: int = 0, dim: int = -1):
+    """The ranks' tensors concatenated along ``dim`` on rank ``dst`` of the tensor-parallel group, None on
+    the others (communication_op.py:74-105)."""
+    if _TP_WORLD == 1:
+        return x
+    if dim < 0:
+        dim += x.dim()
+    if _HOST_STAGED and x.is_cuda:
+        src = x.cpu()
+        parts = [torch.empty_like(src) for _ in range(_TP_WORLD)]
+        dist.all_gather(parts, src, group=_TP_GROUP)
+        return torch.cat(parts, dim=dim).to(x.device) if _TP_RANK == dst else None
+    parts = [torch.empty_like(x) for _ in range(_TP_WORLD)] if _TP_RANK == dst else None
+    dist.gather(x.contiguous(), parts, dst=dist.get_global_rank(_TP_GROUP, dst), group=_TP_GROUP)
+    return torch.cat(parts, dim=dim) if _TP_RANK == dst else None
