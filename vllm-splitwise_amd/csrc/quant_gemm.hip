@@ -354,7 +354,7 @@ gptq_gemm_kwaves_kernel(uint16_t* __restrict__ c, const uint16_t* __restrict__ a
 constexpr int kChunkK = 256;                        // k per A chunk = 16 steps
 constexpr int kARow = kChunkK * 2 + 16;             // LDS bytes per A row; the pad keeps 16 rows on 64 distinct banks
 
-template <int MT, int CP>
+template <int MT, int CP, int CHUNK>
 __global__ void __launch_bounds__(kGemmWaves * 64)
 gptq_gemm_tiled_kernel(uint16_t* __restrict__ c, const uint16_t* __restrict__ a, const uint32_t* __restrict__ qweight,
                        const uint32_t* __restrict__ qzeros, const uint16_t* __restrict__ scales, int M, int N, int K,
@@ -363,10 +363,11 @@ gptq_gemm_tiled_kernel(uint16_t* __restrict__ c, const uint16_t* __restrict__ a,
   using wvec = typename WordVec<CP>::type;
   using svec = typename WordVec<CP>::scale_t;
   constexpr int PF = 8;                               // weight steps in flight
-  constexpr int SPC = kChunkK / 16;                   // steps per chunk
+  constexpr int kARowC = CHUNK * 2 + 16;               // LDS bytes per A row (padded as kARow)
+  constexpr int SPC = CHUNK / 16;                   // steps per chunk
   static_assert(SPC % PF == 0, "ring slots must line up with chunks");
   constexpr int BM = 32 * MT;
-  constexpr int SEGS = kChunkK / 8;                   // 16-byte pieces per A row of a chunk
+  constexpr int SEGS = CHUNK / 8;                   // 16-byte pieces per A row of a chunk
   constexpr int PIECES = BM * SEGS;
   constexpr int PPT = (PIECES + kGemmWaves * 64 - 1) / (kGemmWaves * 64);
   extern __shared__ __attribute__((aligned(16))) char a_lds[];   // 2 x BM x kARow
@@ -382,14 +383,14 @@ gptq_gemm_tiled_kernel(uint16_t* __restrict__ c, const uint16_t* __restrict__ a,
   const int per_xcd = (total + 7) / 8;
   const int work = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
   if (work >= total) return;                          // workgroup-uniform (the grid is padded to 8 * per_xcd)
-  const int row_tile = work % row_tiles;
-  const int col_tile = (work / row_tiles) % col_tiles;
-  const int split = work / (row_tiles * col_tiles);
+  const int split = work % ksplit;                    // the k splits of a tile run side by side on one XCD: the last
+  const int row_tile = (work / ksplit) % row_tiles;   // to arrive finds the others' partial tiles in that XCD's L2
+  const int col_tile = work / (ksplit * row_tiles);
   const int ncol = (col_tile * kGemmWaves + wave) * 32 * CP + CP * j;
   const bool col_ok = ncol < N;
   const int ncl = col_ok ? ncol : 0;
   const int m0 = row_tile * BM;
-  const int chunks = K / kChunkK;
+  const int chunks = K / CHUNK;
   const int c_begin = (int)((int64_t)chunks * split / ksplit), c_end = (int)((int64_t)chunks * (split + 1) / ksplit);
   const int s_begin = SPC * c_begin, s_end = SPC * c_end;
   const int spg = group_size / 16;
@@ -413,7 +414,7 @@ gptq_gemm_tiled_kernel(uint16_t* __restrict__ c, const uint16_t* __restrict__ a,
       const int p = tid + qi * kGemmWaves * 64;
       if (PIECES % (kGemmWaves * 64) == 0 || p < PIECES) {
         const int row = p / SEGS, seg = p % SEGS;
-        a_stage[qi] = *reinterpret_cast<const u32x4*>(a + (size_t)min(m0 + row, M - 1) * K + chunk * kChunkK + seg * 8);
+        a_stage[qi] = *reinterpret_cast<const u32x4*>(a + (size_t)min(m0 + row, M - 1) * K + chunk * CHUNK + seg * 8);
       }
     });
   };
@@ -423,7 +424,7 @@ gptq_gemm_tiled_kernel(uint16_t* __restrict__ c, const uint16_t* __restrict__ a,
       const int p = tid + qi * kGemmWaves * 64;
       if (PIECES % (kGemmWaves * 64) == 0 || p < PIECES) {
         const int row = p / SEGS, seg = p % SEGS;
-        *reinterpret_cast<u32x4*>(a_lds + buf * BM * kARow + row * kARow + seg * 16) = a_stage[qi];
+        *reinterpret_cast<u32x4*>(a_lds + buf * BM * kARowC + row * kARowC + seg * 16) = a_stage[qi];
       }
     });
   };
@@ -464,7 +465,7 @@ gptq_gemm_tiled_kernel(uint16_t* __restrict__ c, const uint16_t* __restrict__ a,
     f16x8 af[MT];
 #pragma unroll
     for (int t = 0; t < MT; ++t)
-      af[t] = *reinterpret_cast<const f16x8*>(a_buf + (32 * t + j) * kARow + step_in_chunk * 32 + half * 16);
+      af[t] = *reinterpret_cast<const f16x8*>(a_buf + (32 * t + j) * kARowC + step_in_chunk * 32 + half * 16);
     uint32_t w[CP];
     if constexpr (CP == 4) { w[0] = wq[slot].x; w[1] = wq[slot].y; w[2] = wq[slot].z; w[3] = wq[slot].w; }
     else { w[0] = wq[slot].x; w[1] = wq[slot].y; }
@@ -483,7 +484,7 @@ gptq_gemm_tiled_kernel(uint16_t* __restrict__ c, const uint16_t* __restrict__ a,
     a_commit(par);
     __syncthreads();
     if (chunk + 1 < c_end) a_fetch(chunk + 1);
-    const char* a_buf = a_lds + par * BM * kARow;
+    const char* a_buf = a_lds + par * BM * kARowC;
     static_for<SPC>([&](auto STEP) {                    // SPC is a multiple of PF: ring slots are compile-time
       constexpr int st = decltype(STEP)::value;
       const int s = SPC * chunk + st;
@@ -853,10 +854,12 @@ int pick_ksplit(int tiles, int units, int min_units, int M, int N, int64_t works
   const int cap = units / (waves * min_units);
   if (ks > cap) ks = cap;
   if (ks > 64) ks = 64;
-  if (const char* env = getenv("SW_QUANT_KSPLIT")) {          // experiments only; clamped like any other choice
+#ifdef SW_QUANT_EXPERIMENT                                     // tuning builds only: never in the shipped library
+  if (const char* env = getenv("SW_QUANT_KSPLIT")) {
     const int forced = atoi(env);
     if (forced >= 1 && forced * waves <= units) ks = forced;
   }
+#endif
   const int64_t per_split = (int64_t)M * N * 4;
   const int64_t room = (workspace_bytes - kCounterBytes) / (per_split > 0 ? per_split : 1);
   if (ks > room) ks = (int)room;
@@ -961,21 +964,27 @@ static int kmajor_gemm(void* c, const void* a, const uint32_t* qweight, const ui
   // unpacked once); 129..256 rows: the LDS-tiled kernel, whose 8 waves share each A chunk
   int cp = 2, mt = M > 64 ? 4 : M > 32 ? 2 : 1;
   bool tiled = M > 128 && K % kChunkK == 0 && group_size % 16 == 0;
-  if (const char* env = getenv("SW_QUANT_CP")) cp = atoi(env) == 4 ? 4 : 2;          // experiments only
+#ifdef SW_QUANT_EXPERIMENT                                     // tuning builds only: never in the shipped library
+  if (const char* env = getenv("SW_QUANT_CP")) cp = atoi(env) == 4 ? 4 : 2;
   if (const char* env = getenv("SW_QUANT_MT")) mt = atoi(env);
   if (const char* env = getenv("SW_QUANT_TILED")) tiled = atoi(env) != 0 && K % kChunkK == 0;
+#endif
   if (mt == 3 || mt > 4) mt = 4;
-  if (tiled && mt > 2) mt = 2;                        // 128-row tiles spill in the tiled kernel
+  // 128-row tiles would unpack a weight word once per four matrix instructions instead of two, but at two
+  // waves per SIMD (256 registers) their 128 accumulators plus the weight ring and the A staging spill
+  // (measured: 2-3x slower than the 64-row tiles, with 256-k and with 128-k chunks alike)
+  if (tiled && mt > 2) mt = 2;
+  const int chunk = kChunkK;
   const int row_tiles = (M + 32 * mt - 1) / (32 * mt);
   if (tiled) {
     const int tile_cols = 32 * cp * kGemmWaves;
     const int col_tiles = (N + tile_cols - 1) / tile_cols;
     const int ks = pick_ksplit(col_tiles * row_tiles, K / kChunkK, 2, M, N, avail, 1, 256);
     const dim3 grid((col_tiles * row_tiles * ks + 7) / 8 * 8);
-    const size_t lds = (size_t)2 * 32 * mt * kARow;
+    const size_t lds = (size_t)2 * 32 * mt * (chunk * 2 + 16);
 #define SW_GPTQ_TILED(MT_, CP_)                                                                                 \
   do {                                                                                                          \
-    auto kern = gptq_gemm_tiled_kernel<MT_, CP_>;                                                               \
+    auto kern = gptq_gemm_tiled_kernel<MT_, CP_, (MT_ > 2 ? 128 : kChunkK)>;                                    \
     if (lds > 64 * 1024)                                                                                        \
       SW_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                     \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                  \
@@ -985,7 +994,8 @@ static int kmajor_gemm(void* c, const void* a, const uint32_t* qweight, const ui
     if (mt == 1 && cp == 2) SW_GPTQ_TILED(1, 2);
     else if (mt == 1) SW_GPTQ_TILED(1, 4);
     else if (mt == 2 && cp == 2) SW_GPTQ_TILED(2, 2);
-    else SW_GPTQ_TILED(2, 4);
+    else if (mt == 2) SW_GPTQ_TILED(2, 4);
+    else SW_GPTQ_TILED(4, 2);
 #undef SW_GPTQ_TILED
   } else {
     const int col_tiles = (N + 32 * cp - 1) / (32 * cp);
