@@ -47,7 +47,7 @@ const char* sw_last_error(void);
  * 2: sw_awq_to_kmajor, sw_int4_kmajor_gemm, sw_int4_kmajor_dequant added.
  * 3: sw_paged_attention_v2_static, sw_paged_attention_v2_static_max_bytes added.
  * 4: sw_kv_push takes max_workgroups. */
-#define SW_ABI_VERSION 4
+#define SW_ABI_VERSION 5
 int sw_abi_version(void);
 
 /* csrc/cuda_utils_kernels.cu:16-35 get_max_shared_memory_per_block_device_attribute:
@@ -303,6 +303,22 @@ int sw_rotary_embedding(const int64_t* positions, void* query, void* key,
                         int head_size, const void* cos_sin_cache, int rot_dim,
                         int is_neox, int64_t query_stride, int64_t key_stride,
                         int act_dtype, void* stream);
+
+/* rotary_embedding (csrc/pos_encoding_kernels.cu:120-171) and reshape_and_cache
+ * (csrc/cache_kernels.cu:228-268) of the same tokens in one launch, for decode steps (one token
+ * per sequence: vllm/model_executor/models/llama.py:150-156 calls the first, layers/attention/
+ * ops/paged_attn.py:56-71 the second).  query and key are rotated in place, the rotated key and
+ * the value go to the caches at slot_mapping[t] (negative: not cached).  Arguments as in the two
+ * entry points above; results identical to calling them one after the other, bit for bit.
+ * head_size, rot_dim/2 (neox) or rot_dim (gpt-j) and head_size - rot_dim must span whole 16-byte
+ * vectors: SW_ERR_INVALID otherwise (callers then make the two calls).                      */
+int sw_rotary_embedding_and_cache(const int64_t* positions, void* query, void* key,
+                                  const void* value, void* key_cache, void* value_cache,
+                                  const int64_t* slot_mapping, int64_t num_tokens, int num_heads,
+                                  int num_kv_heads, int head_size, const void* cos_sin_cache,
+                                  int rot_dim, int is_neox, int block_size, int x,
+                                  int64_t query_stride, int64_t key_stride, int64_t value_stride,
+                                  int act_dtype, int cache_dtype, void* stream);
 
 /* csrc/activation_kernels.cu:66-84 silu_and_mul: out[t, i] = silu(in[t, i]) * in[t, d + i],
  * input [num_tokens, 2 * d] with row stride input_stride, out [num_tokens, d].       */

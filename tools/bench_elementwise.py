@@ -61,6 +61,8 @@ def main():
     kk, vv = k.view(rows, heads, d), v.view(rows, heads, d)
     t = graph_time(lambda: _C.cache_ops.reshape_and_cache(kk, vv, kc, vc, slots, "auto"))
     print(f"reshape_and_cache   {t:7.2f} us  ({4 * rows * hidden * 2 / t / 1e3:7.1f} GB/s)")
+    t = graph_time(lambda: _C.ops.rotary_embedding_and_cache(pos, q, k, v, kc, vc, slots, d, cache, True, "auto"))
+    print(f"rotary + cache, one launch {t:7.2f} us  ({7 * rows * hidden * 2 / t / 1e3:7.1f} GB/s)")
 
 
 if __name__ == "__main__":

@@ -58,6 +58,8 @@ _SIGNATURES = {
                               _c_void_p],
     "sw_rotary_embedding": [_c_void_p, _c_void_p, _c_void_p, _c_i64, _c_int, _c_int, _c_int, _c_void_p, _c_int,
                             _c_int, _c_i64, _c_i64, _c_int, _c_void_p],
+    "sw_rotary_embedding_and_cache": [_c_void_p] * 7 + [_c_i64, _c_int, _c_int, _c_int, _c_void_p, _c_int, _c_int, _c_int,
+                                      _c_int, _c_i64, _c_i64, _c_i64, _c_int, _c_int, _c_void_p],
     "sw_silu_and_mul": [_c_void_p, _c_void_p, _c_i64, _c_int, _c_i64, _c_int, _c_void_p],
     "sw_ipc_get_mem_handle": [_c_void_p, _c_void_p],
     "sw_mem_address_range": [_c_void_p, ctypes.POINTER(_c_void_p), ctypes.POINTER(_c_i64)],
@@ -97,7 +99,7 @@ def library_path() -> str:
     return _LIB_PATH
 
 
-ABI_VERSION = 4                # SW_ABI_VERSION of include/splitwise_hip.h this binding was written against
+ABI_VERSION = 5                # SW_ABI_VERSION of include/splitwise_hip.h this binding was written against
 
 
 def load_library() -> ctypes.CDLL:
@@ -460,6 +462,34 @@ def rotary_embedding(positions: torch.Tensor, query: torch.Tensor, key: torch.Te
             1 if is_neox else 0, q_stride, k_stride, _act_dtype(query), _stream(query)))
 
 
+def rotary_embedding_and_cache(positions: torch.Tensor, query: torch.Tensor, key: torch.Tensor, value: torch.Tensor,
+                               key_cache: torch.Tensor, value_cache: torch.Tensor, slot_mapping: torch.Tensor,
+                               head_size: int, cos_sin_cache: torch.Tensor, is_neox: bool, kv_cache_dtype: str) -> None:
+    """``ops.rotary_embedding`` then ``cache_ops.reshape_and_cache`` on the same tokens, one launch
+    (decode steps); no single counterpart in the reference, results identical to the two calls."""
+    _require_cuda(positions, query, key, value, key_cache, value_cache, slot_mapping, cos_sin_cache)
+    if positions.dtype != torch.int64 or not positions.is_contiguous():
+        raise RuntimeError("rotary_embedding_and_cache: positions must be contiguous int64")
+    if slot_mapping.dtype != torch.int64 or not slot_mapping.is_contiguous():
+        raise RuntimeError("rotary_embedding_and_cache: slot_mapping must be contiguous int64")
+    if cos_sin_cache.dtype != query.dtype:
+        raise RuntimeError("rotary_embedding_and_cache: cos_sin_cache must have the dtype of query")
+    q_rows, q_stride = _rows(query)
+    k_rows, k_stride = _rows(key)
+    v_rows, v_stride = _rows(value)
+    if not (q_rows == k_rows == v_rows == positions.numel() == slot_mapping.numel()):
+        raise RuntimeError("rotary_embedding_and_cache: positions / slots / query / key / value disagree on the "
+                           "token count")
+    act = _act_dtype(query)
+    with torch.cuda.device(query.device):
+        _check(load_library().sw_rotary_embedding_and_cache(
+            positions.data_ptr(), query.data_ptr(), key.data_ptr(), value.data_ptr(), key_cache.data_ptr(),
+            value_cache.data_ptr(), slot_mapping.data_ptr(), q_rows, query.shape[-1] // head_size,
+            key.shape[-1] // head_size, head_size, cos_sin_cache.data_ptr(), cos_sin_cache.shape[1],
+            1 if is_neox else 0, key_cache.shape[3], key_cache.shape[4], q_stride, k_stride, v_stride, act,
+            _cache_dtype(kv_cache_dtype, act), _stream(query)))
+
+
 def silu_and_mul(out: torch.Tensor, input: torch.Tensor) -> None:
     """``ops.silu_and_mul`` (csrc/activation_kernels.cu:66-84)."""
     _require_cuda(out, input)
@@ -733,6 +763,7 @@ ops = SimpleNamespace(
     rms_norm=rms_norm,
     fused_add_rms_norm=fused_add_rms_norm,
     rotary_embedding=rotary_embedding,
+    rotary_embedding_and_cache=rotary_embedding_and_cache,
     silu_and_mul=silu_and_mul,
     gptq_shuffle=gptq_shuffle,
     gptq_gemm=gptq_gemm,

@@ -143,9 +143,24 @@ class Attention(nn.Module):
 
     def forward(self, query: torch.Tensor, key: torch.Tensor, value: torch.Tensor,
                 key_cache: Optional[torch.Tensor], value_cache: Optional[torch.Tensor],
-                input_metadata: InputMetadata) -> torch.Tensor:
-        """query [..., H*D], key / value [..., KVH*D] (views of the fused qkv output are fine)."""
+                input_metadata: InputMetadata, rotary=None, positions: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """query [..., H*D], key / value [..., KVH*D] (views of the fused qkv output are fine).
+
+        ``rotary`` / ``positions``: a model that has NOT applied its rotary embedding yet hands the
+        module and the positions over; a decode step then rotates q / k and writes the cache in one
+        launch, any other step applies ``rotary`` first and goes on as the reference does."""
         out_shape = query.shape
+        fused_cache_write = False
+        if rotary is not None:
+            if (not input_metadata.is_prompt and key_cache is not None and value_cache is not None
+                    and rotary.fusable_with_cache_write(query.dtype)):
+                _C.ops.rotary_embedding_and_cache(positions.flatten(), query, key, value, key_cache, value_cache,
+                                                  input_metadata.slot_mapping.flatten(), self.head_size,
+                                                  rotary.cos_sin_cache, rotary.is_neox_style,
+                                                  input_metadata.kv_cache_dtype)
+                fused_cache_write = True
+            else:
+                query, key = rotary(positions, query, key)
         query = query.reshape(-1, self.num_heads, self.head_size) if query.dim() != 2 else \
             query.view(-1, self.num_heads, self.head_size)
         key = key.view(-1, self.num_kv_heads, self.head_size) if key.dim() == 2 else \
@@ -155,7 +170,7 @@ class Attention(nn.Module):
         if self.alibi_slopes is not None and self.alibi_slopes.device != query.device:
             self.alibi_slopes = self.alibi_slopes.to(query.device)
 
-        if key_cache is not None and value_cache is not None:
+        if key_cache is not None and value_cache is not None and not fused_cache_write:
             PagedAttentionImpl.reshape_and_cache(key, value, key_cache, value_cache, input_metadata)
 
         if input_metadata.is_prompt:

@@ -81,6 +81,14 @@ class RotaryEmbedding(nn.Module):
                                 self.is_neox_style)
         return query, key
 
+    def fusable_with_cache_write(self, dtype: torch.dtype) -> bool:
+        """Whether ``ops.rotary_embedding_and_cache`` takes this geometry: the rotated part (its halves for
+        the neox pairing), the rest of the head and the head itself span whole 16-byte vectors."""
+        n = 16 // torch.empty((), dtype=dtype).element_size()
+        rot = self.rotary_dim // 2 if self.is_neox_style else self.rotary_dim
+        return (self.rotary_dim % 2 == 0 and rot % n == 0 and (self.head_size - self.rotary_dim) % n == 0
+                and self.head_size % n == 0)
+
 
 class SiluAndMul(nn.Module):
     def _forward(self, x: torch.Tensor) -> torch.Tensor:

@@ -54,8 +54,8 @@ class LlamaAttention(nn.Module):
     def forward(self, positions, hidden_states, kv_cache: KVCache, input_metadata: InputMetadata):
         qkv = self.qkv_proj(hidden_states)
         q, k, v = qkv.split([self.q_size, self.kv_size, self.kv_size], dim=-1)
-        q, k = self.rotary_emb(positions, q, k)
-        attn = self.attn(q, k, v, kv_cache[0], kv_cache[1], input_metadata)
+        # decode steps rotate q / k and write the cache in one launch; other steps rotate first
+        attn = self.attn(q, k, v, kv_cache[0], kv_cache[1], input_metadata, rotary=self.rotary_emb, positions=positions)
         return self.o_proj(attn)
 
 
