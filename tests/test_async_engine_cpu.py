@@ -136,8 +136,9 @@ def test_http_generate_and_openai_routes():
         with client.stream("POST", "/v1/completions", json={"prompt": prompt, "max_tokens": 3, "temperature": 0.0,
                                                             "ignore_eos": True, "stream": True}) as resp:
             lines = [ln for ln in resp.iter_lines() if ln.startswith("data: ")]
-        assert lines[-1] == "data: [DONE]" and len(lines) == 4
+        assert lines[-1] == "data: [DONE]" and len(lines) == 5          # 3 tokens, the usage count, the end mark
         assert json.loads(lines[2][6:])["choices"][0]["finish_reason"] == "length"
+        assert json.loads(lines[3][6:])["usage"] == {"prompt_tokens": 8, "completion_tokens": 3, "total_tokens": 11}
         assert client.post("/v1/chat/completions", json={"messages": [{"role": "user", "content": "hi"}]}).status_code == 400
 
 

@@ -147,6 +147,10 @@ class CacheConfig:
         self.num_gpu_blocks: Optional[int] = None
         self.num_cpu_blocks: Optional[int] = None
 
+    def metrics_info(self) -> dict:
+        """Label set of the ``vllm:cache_config`` info series: every setting as a string (config.py:352-355)."""
+        return {key: str(value) for key, value in self.__dict__.items()}
+
 
 class ParallelConfig:
     """vllm/config.py:391-471.  With sep_prompt_token the world is a prompt pool followed by

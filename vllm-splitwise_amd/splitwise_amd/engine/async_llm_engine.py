@@ -152,7 +152,9 @@ class AsyncLLMEngine:
         if exc is not None:
             self._errored_with = exc
             if self._request_tracker is not None:
-                self._request_tracker.propagate_exception(AsyncEngineDeadError(f"engine loop failed: {exc!r}"))
+                dead = AsyncEngineDeadError(f"engine loop failed: {exc!r}")
+                dead.__cause__ = exc                 # waiting requests see where the loop died, not only that it did
+                self._request_tracker.propagate_exception(dead)
 
     # ------------------------------------------------------------------- loop
     async def engine_step(self) -> bool:

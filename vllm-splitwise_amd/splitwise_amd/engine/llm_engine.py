@@ -12,6 +12,7 @@ from ..core.scheduler import Scheduler, SchedulerOutputs
 from ..outputs import RequestOutput
 from ..sampling_params import SamplingParams
 from ..sequence import (SamplerOutput, Sequence, SequenceGroup, SequenceGroupMetadata, SequenceStatus)
+from ..transformers_utils.tokenizer import detokenize_incrementally, get_tokenizer
 from .arg_utils import EngineArgs
 from .metrics import StatLogger, Stats
 
@@ -46,7 +47,10 @@ class LLMEngine:
                                                  device_config, num_gpu_blocks_override=num_gpu_blocks_override)
         self.scheduler = Scheduler(scheduler_config, cache_config, None,
                                    track_prompt_blocks=parallel_config.sep_prompt_token)
-        self.stat_logger = StatLogger(local_interval=5.0) if log_stats else None
+        self.stat_logger = None
+        if log_stats:
+            self.stat_logger = StatLogger(local_interval=5.0, labels=dict(model_name=model_config.model))
+            self.stat_logger.info("cache_config", cache_config)
         # split pools: run a prompt step and a decode step concurrently when the executor can
         self.overlap_pools = parallel_config.sep_prompt_token and hasattr(self.model_executor, "execute_split")
         self._slot_epoch: Dict[int, int] = {}
@@ -79,6 +83,8 @@ class LLMEngine:
     @classmethod
     def from_engine_args(cls, engine_args: EngineArgs, **kwargs) -> "LLMEngine":
         configs = engine_args.create_engine_configs()
+        if kwargs.get("tokenizer") is None and engine_args.tokenizer:
+            kwargs["tokenizer"] = get_tokenizer(engine_args.tokenizer)
         return cls(*configs, num_gpu_blocks_override=engine_args.num_gpu_blocks_override, **kwargs)
 
     # ----------------------------------------------------------------- requests
@@ -109,7 +115,43 @@ class LLMEngine:
                 or bool(self.scheduler.held_after_abort))
 
     # --------------------------------------------------------------------- step
+    def _decode_sequence(self, seq: Sequence, params: SamplingParams) -> None:
+        """Appends the text of the newest token to ``seq.output_text`` (llm_engine.py:859-877)."""
+        if self.tokenizer is None:
+            return
+        new_tokens, new_text, *offsets = detokenize_incrementally(
+            self.tokenizer, seq.get_token_ids(), seq.tokens, seq.prefix_offset, seq.read_offset,
+            skip_special_tokens=params.skip_special_tokens,
+            spaces_between_special_tokens=params.spaces_between_special_tokens)
+        if params.logprobs is not None and seq.output_logprobs and seq.output_logprobs[-1]:
+            # the text each candidate would have added in the sampled token's place (llm_engine.py:835-857)
+            ids = seq.get_token_ids()
+            for token_id, entry in seq.output_logprobs[-1].items():
+                if token_id == ids[-1]:
+                    entry.decoded_token = new_text
+                elif entry.decoded_token is None:
+                    _, entry.decoded_token, _, _ = detokenize_incrementally(
+                        self.tokenizer, ids[:-1] + [token_id], seq.tokens, seq.prefix_offset, seq.read_offset,
+                        skip_special_tokens=params.skip_special_tokens,
+                        spaces_between_special_tokens=params.spaces_between_special_tokens)
+        seq.tokens = new_tokens if seq.tokens is None else seq.tokens + new_tokens
+        seq.prefix_offset, seq.read_offset = offsets
+        seq.output_text += new_text
+
+    @staticmethod
+    def _stop_string_hit(seq: Sequence, params: SamplingParams) -> bool:
+        """A stop string ends the output and is cut from it unless asked to stay (llm_engine.py:881-888)."""
+        for stop_str in params.stop:
+            if stop_str and seq.output_text.endswith(stop_str):
+                if not params.include_stop_str_in_output:
+                    seq.output_text = seq.output_text[:-len(stop_str)]
+                return True
+        return False
+
     def _check_stop(self, seq: Sequence, params: SamplingParams) -> None:
+        if self._stop_string_hit(seq, params):
+            seq.status = SequenceStatus.FINISHED_STOPPED
+            return
         last = seq.get_last_token_id()
         if last in params.stop_token_ids:
             seq.status = SequenceStatus.FINISHED_STOPPED
@@ -137,8 +179,7 @@ class LLMEngine:
             seq = group.get_seqs(status=SequenceStatus.RUNNING)[0]
             sample = out.samples[0]
             seq.append_token_id(sample.output_token, sample.logprobs)
-            if self.tokenizer is not None:
-                seq.output_text = self.tokenizer.decode(seq.get_output_token_ids())
+            self._decode_sequence(seq, group.sampling_params)
             self._check_stop(seq, group.sampling_params)
             if seq.is_finished():
                 self.scheduler.free_seq(seq)
@@ -212,11 +253,12 @@ class LLMEngine:
             seq.fill_placeholder(sample.output_token, sample.logprobs)
             if seq.status == SequenceStatus.FINISHED_ABORTED:
                 continue
-            if self.tokenizer is not None:
-                seq.output_text = self.tokenizer.decode(seq.get_output_token_ids())
+            self._decode_sequence(seq, group.sampling_params)
             if seq.is_finished():
-                # ended by length when the step was launched; a stop token takes precedence as in _check_stop
-                if sample.output_token in group.sampling_params.stop_token_ids:
+                # ended by length when the step was launched; a stop string or token takes precedence as in
+                # _check_stop
+                if (self._stop_string_hit(seq, group.sampling_params)
+                        or sample.output_token in group.sampling_params.stop_token_ids):
                     seq.status = SequenceStatus.FINISHED_STOPPED
                 self.scheduler.free_seq(seq)            # no-op when the blocks went back at launch
             else:
@@ -346,6 +388,8 @@ class LLMEngine:
     def _get_stats(self, scheduler_outputs: SchedulerOutputs, scheduled: List[SequenceGroup], now: float) -> Stats:
         total = self.cache_config.num_gpu_blocks or 1
         free = self.scheduler.block_manager.get_num_free_gpu_blocks()
+        total_cpu = self.cache_config.num_cpu_blocks or 0
+        cpu_usage = 1.0 - self.scheduler.block_manager.get_num_free_cpu_blocks() / total_cpu if total_cpu > 0 else 0.0
         prompt_tokens = scheduler_outputs.num_batched_tokens if scheduler_outputs.prompt_run else 0
         gen_tokens = 0 if scheduler_outputs.prompt_run else scheduler_outputs.num_batched_tokens
         ttft, tpot, e2e = [], [], []
@@ -356,7 +400,7 @@ class LLMEngine:
                 e2e.append(now - g.metrics.arrival_time)
         return Stats(now=now, num_running=len(self.scheduler.running), num_swapped=len(self.scheduler.swapped),
                      num_waiting=len(self.scheduler.waiting), gpu_cache_usage=1.0 - free / total,
-                     cpu_cache_usage=0.0, num_prompt_tokens=prompt_tokens, num_generation_tokens=gen_tokens,
+                     cpu_cache_usage=cpu_usage, num_prompt_tokens=prompt_tokens, num_generation_tokens=gen_tokens,
                      time_to_first_tokens=ttft, time_per_output_tokens=tpot, time_e2e_requests=e2e)
 
     def check_health(self) -> None:

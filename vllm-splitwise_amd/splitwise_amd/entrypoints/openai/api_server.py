@@ -1,54 +1,61 @@
-"""OpenAI-style routes (vllm/entrypoints/openai/api_server.py:150-196): ``/metrics``, ``/health``,
-``/v1/models``, ``/v1/completions`` (plain and server-sent-event streaming) and
-``/v1/chat/completions``.  Prompts may be strings (with a tokenizer on the engine), one list of
-token ids, or a list of such lists, as the OpenAI completions API allows.  Chat needs a
-tokenizer with a chat template and answers 400 without one.
+"""OpenAI-style HTTP front (vllm/entrypoints/openai/api_server.py:36-265): ``/health``, ``/metrics``
+(Prometheus), ``/v1/models``, ``/v1/completions``, ``/v1/chat/completions``; optional bearer key,
+CORS settings, chat template and response role from the command line.
 """
 import argparse
 import json
-import time
-import uuid
-from typing import AsyncGenerator, List, Optional, Union
+from typing import List, Optional
 
 from fastapi import FastAPI, Request
-from fastapi.responses import JSONResponse, Response, StreamingResponse
+from fastapi.exceptions import RequestValidationError
+from fastapi.middleware.cors import CORSMiddleware
+from fastapi.responses import JSONResponse, Response
 
 from ...engine.arg_utils import EngineArgs
 from ...engine.async_llm_engine import AsyncLLMEngine
-from ...sampling_params import SamplingParams
+from .serving_chat import OpenAIServingChat
+from .serving_completion import OpenAIServingCompletion
+from .serving_engine import error_response
 
 
-def _error(message: str, status: int = 400, kind: str = "invalid_request_error") -> JSONResponse:
-    return JSONResponse({"object": "error", "message": message, "type": kind, "code": status}, status_code=status)
+def build_app(engine: AsyncLLMEngine, served_model: str, response_role: str = "assistant",
+              chat_template: Optional[str] = None, api_key: Optional[str] = None, root_path: Optional[str] = None,
+              allowed_origins: Optional[List[str]] = None, allow_credentials: bool = False,
+              allowed_methods: Optional[List[str]] = None, allowed_headers: Optional[List[str]] = None) -> FastAPI:
+    app = FastAPI(root_path=root_path or "")
+    app.add_middleware(CORSMiddleware, allow_origins=allowed_origins or ["*"], allow_credentials=allow_credentials,
+                       allow_methods=allowed_methods or ["*"], allow_headers=allowed_headers or ["*"])
+    completion = OpenAIServingCompletion(engine, served_model)
+    chat = OpenAIServingChat(engine, served_model, response_role, chat_template)
 
-
-def _prompts(raw) -> List[Union[str, List[int]]]:
-    if isinstance(raw, str):
-        return [raw]
-    if isinstance(raw, list) and raw and all(isinstance(t, int) for t in raw):
-        return [raw]
-    if isinstance(raw, list) and raw and all(isinstance(p, (str, list)) for p in raw):
-        return list(raw)
-    raise ValueError("prompt must be a string, a list of token ids, or a list of those")
-
-
-def _sampling_params(body: dict) -> SamplingParams:
-    return SamplingParams(n=body.get("n", 1), best_of=body.get("best_of"), temperature=body.get("temperature", 1.0),
-                          top_p=body.get("top_p", 1.0), top_k=body.get("top_k", -1), stop=body.get("stop"),
-                          stop_token_ids=body.get("stop_token_ids"), ignore_eos=body.get("ignore_eos", False),
-                          max_tokens=body.get("max_tokens", 16), logprobs=body.get("logprobs"),
-                          seed=body.get("seed"))
-
-
-def build_app(engine: AsyncLLMEngine, served_model: str) -> FastAPI:
-    app = FastAPI()
     try:                                            # /metrics (openai/api_server.py:150-152)
         from prometheus_client import make_asgi_app
-        from ...engine.metrics import _metrics
-        _metrics()                                  # registers the vllm:* series even before the first step
+        from ...engine import metrics
+        metrics.ensure_registered(served_model)     # the vllm:* series exist before the first step
         app.mount("/metrics", make_asgi_app())
     except ImportError:                             # pragma: no cover - the front works without it
         pass
+
+    if api_key:                                     # openai/api_server.py:215-229
+        @app.middleware("http")
+        async def authentication(request: Request, call_next):
+            prefix = (root_path or "") + "/v1"
+            if request.url.path.startswith(prefix) and request.headers.get("Authorization") != "Bearer " + api_key:
+                return JSONResponse({"error": "Unauthorized"}, status_code=401)
+            return await call_next(request)
+
+    @app.exception_handler(RequestValidationError)
+    async def validation_exception_handler(_, exc):
+        return error_response(str(exc))
+
+    async def json_body(request: Request):
+        try:
+            body = await request.json()
+        except (json.JSONDecodeError, UnicodeDecodeError) as e:
+            return None, error_response(f"request body is not valid JSON: {e}")
+        if not isinstance(body, dict):
+            return None, error_response("request body must be a JSON object")
+        return body, None
 
     @app.get("/health")
     async def health() -> Response:
@@ -56,108 +63,52 @@ def build_app(engine: AsyncLLMEngine, served_model: str) -> FastAPI:
         return Response(status_code=200)
 
     @app.get("/v1/models")
-    async def models() -> JSONResponse:
-        cfg = await engine.get_model_config()
-        return JSONResponse({"object": "list", "data": [{"id": served_model, "object": "model",
-                                                         "created": int(time.time()), "owned_by": "splitwise_amd",
-                                                         "max_model_len": cfg.max_model_len}]})
+    async def show_available_models() -> JSONResponse:
+        return JSONResponse(completion.show_available_models())
 
     @app.post("/v1/completions")
-    async def completions(request: Request):
-        body = await request.json()
-        if body.get("model") not in (None, served_model):
-            return _error(f"The model `{body.get('model')}` does not exist.", 404, "NotFoundError")
-        try:
-            prompts = _prompts(body.get("prompt"))
-            params = _sampling_params(body)
-        except (TypeError, ValueError, NotImplementedError) as e:
-            return _error(str(e))
-        request_id = f"cmpl-{uuid.uuid4().hex}"
-        created = int(time.time())
-        gens = []
-        for i, p in enumerate(prompts):
-            text, ids = (p, None) if isinstance(p, str) else (None, p)
-            gens.append(engine.generate(text, params, f"{request_id}-{i}", prompt_token_ids=ids))
-
-        def chunk(index: int, out, delta_from: int, final: bool) -> dict:
-            o = out.outputs[0]
-            return {"id": request_id, "object": "text_completion", "created": created, "model": served_model,
-                    "choices": [{"index": index, "text": o.text[delta_from:] if delta_from >= 0 else o.text,
-                                 "token_ids": o.token_ids, "logprobs": None,
-                                 "finish_reason": o.finish_reason if final else None}]}
-
-        if body.get("stream", False):
-            async def sse() -> AsyncGenerator[str, None]:
-                try:
-                    for i, gen in enumerate(gens):
-                        seen = 0
-                        async for out in gen:
-                            yield f"data: {json.dumps(chunk(i, out, seen, out.finished))}\n\n"
-                            seen = len(out.outputs[0].text)
-                except (ValueError, NotImplementedError) as e:
-                    yield f"data: {json.dumps({'error': str(e)})}\n\n"
-                yield "data: [DONE]\n\n"
-            return StreamingResponse(sse(), media_type="text/event-stream")
-
-        choices, prompt_tokens, completion_tokens = [], 0, 0
-        try:
-            for i, gen in enumerate(gens):
-                final = None
-                async for out in gen:
-                    if await request.is_disconnected():
-                        await engine.abort([f"{request_id}-{j}" for j in range(len(gens))])
-                        return _error("Client disconnected", 499)
-                    final = out
-                choices += chunk(i, final, -1, True)["choices"]
-                prompt_tokens += len(final.prompt_token_ids)
-                completion_tokens += len(final.outputs[0].token_ids)
-        except (ValueError, NotImplementedError) as e:
-            return _error(str(e))
-        return JSONResponse({"id": request_id, "object": "text_completion", "created": created, "model": served_model,
-                             "choices": choices,
-                             "usage": {"prompt_tokens": prompt_tokens, "completion_tokens": completion_tokens,
-                                       "total_tokens": prompt_tokens + completion_tokens}})
+    async def create_completion(request: Request):
+        body, err = await json_body(request)
+        return err if err is not None else await completion.create_completion(body, request)
 
     @app.post("/v1/chat/completions")
-    async def chat_completions(request: Request):
-        body = await request.json()
-        tokenizer = engine.engine.tokenizer
-        if tokenizer is None or not hasattr(tokenizer, "apply_chat_template"):
-            return _error("chat completions need a tokenizer with a chat template; this engine was started "
-                          "without one (send token ids to /v1/completions instead)")
-        try:
-            prompt = tokenizer.apply_chat_template(conversation=body["messages"], tokenize=False,
-                                                   add_generation_prompt=body.get("add_generation_prompt", True))
-            params = _sampling_params(body)
-        except Exception as e:                       # noqa: BLE001 - template errors are the caller's
-            return _error(str(e))
-        request_id = f"chatcmpl-{uuid.uuid4().hex}"
-        final = None
-        async for out in engine.generate(prompt, params, request_id):
-            final = out
-        o = final.outputs[0]
-        n_prompt, n_out = len(final.prompt_token_ids), len(o.token_ids)
-        return JSONResponse({"id": request_id, "object": "chat.completion", "created": int(time.time()),
-                             "model": served_model,
-                             "choices": [{"index": 0, "message": {"role": "assistant", "content": o.text},
-                                          "finish_reason": o.finish_reason}],
-                             "usage": {"prompt_tokens": n_prompt, "completion_tokens": n_out,
-                                       "total_tokens": n_prompt + n_out}})
+    async def create_chat_completion(request: Request):
+        body, err = await json_body(request)
+        return err if err is not None else await chat.create_chat_completion(body, request)
 
     return app
 
 
-def main() -> None:
-    import uvicorn
-    parser = argparse.ArgumentParser()
+def make_arg_parser() -> argparse.ArgumentParser:
+    """The reference's front-end flags (openai/api_server.py:57-139), then the engine's."""
+    parser = argparse.ArgumentParser(description="OpenAI-compatible RESTful API server.")
     parser.add_argument("--host", type=str, default=None)
     parser.add_argument("--port", type=int, default=8000)
+    parser.add_argument("--allow-credentials", action="store_true")
+    parser.add_argument("--allowed-origins", type=json.loads, default=["*"])
+    parser.add_argument("--allowed-methods", type=json.loads, default=["*"])
+    parser.add_argument("--allowed-headers", type=json.loads, default=["*"])
+    parser.add_argument("--api-key", type=str, default=None,
+                        help="If provided, the server will require this key to be presented in the header.")
     parser.add_argument("--served-model-name", type=str, default=None)
-    parser = EngineArgs.add_cli_args(parser)
-    args = parser.parse_args()
+    parser.add_argument("--chat-template", type=str, default=None,
+                        help="File path of a chat template, or the template in single-line form.")
+    parser.add_argument("--response-role", type=str, default="assistant")
+    parser.add_argument("--ssl-keyfile", type=str, default=None)
+    parser.add_argument("--ssl-certfile", type=str, default=None)
+    parser.add_argument("--root-path", type=str, default=None)
+    return EngineArgs.add_cli_args(parser)
+
+
+def main() -> None:
+    import uvicorn
+    args = make_arg_parser().parse_args()
     engine = AsyncLLMEngine.from_engine_args(EngineArgs.from_cli_args(args))
-    uvicorn.run(build_app(engine, args.served_model_name or args.model), host=args.host, port=args.port,
-                log_level="info", timeout_keep_alive=5)
+    app = build_app(engine, args.served_model_name or args.model, args.response_role, args.chat_template,
+                    args.api_key, args.root_path, args.allowed_origins, args.allow_credentials,
+                    args.allowed_methods, args.allowed_headers)
+    uvicorn.run(app, host=args.host, port=args.port, log_level="info", timeout_keep_alive=5,
+                ssl_keyfile=args.ssl_keyfile, ssl_certfile=args.ssl_certfile)
 
 
 if __name__ == "__main__":

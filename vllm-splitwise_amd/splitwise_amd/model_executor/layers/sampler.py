@@ -40,14 +40,21 @@ def _host_to_device(values, dtype: torch.dtype, device: torch.device) -> torch.T
     return t.to(device)
 
 
-def _build_output(seq_groups, ids: List[int], chosen_lp: Optional[List[float]]) -> SamplerOutput:
+def _build_output(seq_groups, ids: List[int], chosen_lp: Optional[List[float]], top=None) -> SamplerOutput:
+    """``top``: (log-probs, token ids) of the most likely tokens of every row, as nested lists, when some
+    request asked for ``logprobs``; a row's dict holds the sampled token and its request's top-k
+    (sampler.py:540-587 of the reference)."""
     outputs: List[SequenceGroupOutput] = []
     row = 0
-    for seq_ids, _ in seq_groups:
+    for seq_ids, params in seq_groups:
         samples = []
         for seq_id in seq_ids:
             lp = 0.0 if chosen_lp is None else chosen_lp[row]
-            samples.append(SequenceOutput(seq_id, ids[row], {ids[row]: Logprob(lp)}))
+            entry = {ids[row]: Logprob(lp)}
+            if top is not None and params.logprobs:
+                for tok_lp, tok in zip(top[0][row][:params.logprobs], top[1][row][:params.logprobs]):
+                    entry.setdefault(tok, Logprob(tok_lp))
+            samples.append(SequenceOutput(seq_id, ids[row], entry))
             row += 1
         outputs.append(SequenceGroupOutput(samples, None))
     return SamplerOutput(outputs=outputs)
@@ -58,9 +65,11 @@ class PendingSamples:
     next step reads its input tokens from it), a copy is on its way to pinned host memory, and
     ``resolve`` waits for that copy only."""
 
-    def __init__(self, seq_groups, next_ids: torch.Tensor, chosen_lp: Optional[torch.Tensor]) -> None:
+    def __init__(self, seq_groups, next_ids: torch.Tensor, chosen_lp: Optional[torch.Tensor], top=None) -> None:
         self.seq_groups = seq_groups
         self.next_ids = next_ids
+        self._top = None if top is None else tuple(
+            torch.empty(t.shape, dtype=t.dtype, pin_memory=t.is_cuda).copy_(t, non_blocking=True) for t in top)
         self.row_of: Dict[int, int] = {}
         for seq_ids, _ in seq_groups:
             for seq_id in seq_ids:
@@ -93,7 +102,8 @@ class PendingSamples:
         checks, self.after_sync = self.after_sync, []
         for check in checks:         # e.g. the worker's look at its hand-off / all-reduce status words
             check()
-        return _build_output(self.seq_groups, self._ids.tolist(), None if self._lp is None else self._lp.tolist())
+        return _build_output(self.seq_groups, self._ids.tolist(), None if self._lp is None else self._lp.tolist(),
+                             None if self._top is None else tuple(t.tolist() for t in self._top))
 
 
 class Sampler(nn.Module):
@@ -148,12 +158,13 @@ class Sampler(nn.Module):
         assert len(rows) == logits.shape[0], (len(rows), logits.shape)
         all_greedy = all(p.sampling_type == SamplingType.GREEDY for p in rows)
         want_logprobs = any(p.logprobs is not None for p in rows)
+        top = None
         if all_greedy and not want_logprobs:
             # fast path: argmax of the logits equals argmax of the log-probs; the sampled token's
             # log-probability is its logit minus the row's log-sum-exp (sampler.py:417 of the reference
             # takes it from the full log-softmax)
-            top, next_ids = torch.max(logits, dim=-1)
-            chosen_lp = top - torch.logsumexp(logits, dim=-1)
+            best, next_ids = torch.max(logits, dim=-1)
+            chosen_lp = best - torch.logsumexp(logits, dim=-1)
         else:
             temps = [p.temperature if p.temperature >= _EPS else 1.0 for p in rows]
             if any(t != 1.0 for t in temps):
@@ -178,7 +189,12 @@ class Sampler(nn.Module):
                                             logits.device)
                 next_ids = torch.where(is_greedy, greedy_ids, random_ids)
             chosen_lp = logprobs.gather(1, next_ids.unsqueeze(1)).squeeze(1)
+            most = max((p.logprobs or 0) for p in rows)
+            if most > 0:
+                top = torch.topk(logprobs, min(most, logprobs.shape[1]), dim=-1)
+                top = (top.values, top.indices)
         if md.defer:
-            return PendingSamples(md.seq_groups, next_ids, chosen_lp)
+            return PendingSamples(md.seq_groups, next_ids, chosen_lp, top)
         # the one device -> host sync of the step
-        return _build_output(md.seq_groups, next_ids.tolist(), None if chosen_lp is None else chosen_lp.tolist())
+        return _build_output(md.seq_groups, next_ids.tolist(), None if chosen_lp is None else chosen_lp.tolist(),
+                             None if top is None else (top[0].tolist(), top[1].tolist()))

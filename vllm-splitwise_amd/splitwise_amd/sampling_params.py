@@ -20,7 +20,8 @@ class SamplingParams:
                  stop: Optional[Union[str, List[str]]] = None, stop_token_ids: Optional[List[int]] = None,
                  ignore_eos: bool = False, max_tokens: Optional[int] = 16, logprobs: Optional[int] = None,
                  prompt_logprobs: Optional[int] = None, skip_special_tokens: bool = True,
-                 seed: Optional[int] = None, include_stop_str_in_output: bool = False) -> None:
+                 seed: Optional[int] = None, include_stop_str_in_output: bool = False,
+                 spaces_between_special_tokens: bool = True) -> None:
         self.n = n
         self.best_of = best_of if best_of is not None else n
         self.temperature = temperature
@@ -36,6 +37,7 @@ class SamplingParams:
         self.skip_special_tokens = skip_special_tokens
         self.seed = seed
         self.include_stop_str_in_output = include_stop_str_in_output
+        self.spaces_between_special_tokens = spaces_between_special_tokens
         self._verify()
 
     def _verify(self) -> None:
@@ -52,6 +54,8 @@ class SamplingParams:
             raise ValueError(f"top_k must be -1 (disable), or at least 1, got {self.top_k}.")
         if self.max_tokens is not None and self.max_tokens < 1:
             raise ValueError(f"max_tokens must be at least 1, got {self.max_tokens}.")
+        if self.logprobs is not None and self.logprobs < 0:
+            raise ValueError(f"logprobs must be non-negative, got {self.logprobs}.")
         if self.use_beam_search:
             raise NotImplementedError("beam search is outside the scope of this build")
         if self.best_of != 1 and self.temperature < _EPS:
