@@ -18,15 +18,22 @@
 //     O^T += V^T . P^T (32x32 accumulator rows are the next product's k index); the A
 //     operand V^T is read from a row-major LDS image of the V tile with the transposing
 //     ds_read_b64_tr_b16, 4 keys per read.
-//   * the 4 waves of a workgroup (128 query rows) share every stage of 32 keys: K and V rows go
+//   * the 4 waves of a workgroup (128 query rows) share every stage of 64 keys: K and V rows go
 //     global -> registers (while the previous stage is in use) -> LDS, one barrier per stage;
 //     K fragments are 16-byte LDS reads (8 contiguous head elements of one key per lane).
+//   * a wave works on the stage's two score tiles together: two independent chains of Q.K products,
+//     one softmax update over 32 scores per lane, then the P.V products of both with the exponentials
+//     spread among them.  The vector work of a tile (~100 instructions after the measures below) is of
+//     the size of its 16 matrix instructions, and a SIMD holds two waves: what one wave leaves idle, the
+//     other mostly fills (counters: matrix pipe busy a third of the time, vector pipe two fifths).
 //   * scores live in the log2 domain (one v_exp_f32 per probability); the output accumulator
-//     is rescaled only when some lane's running maximum moved.
+//     is rescaled only when some lane's running maximum has grown by more than 2^8.
 //   * a cached prefix (sw_context_attention) is handled before the causal part, its K and V^T
 //     fragments loaded straight from the paged cache layouts.
 #include "common.cuh"
 #include <float.h>
+#include <algorithm>
+#include <type_traits>
 
 namespace sw {
 
@@ -55,7 +62,8 @@ template <> struct Mfma<f16_t> {
 constexpr int kPfWaves = 4;
 constexpr int kPfRows = 32;                          // query rows per wave
 constexpr int kPfKeys = 32;                          // keys per score tile (one MFMA output block)
-constexpr int kPfStage = 32;                         // keys per shared LDS stage (a multiple of kPfKeys)
+// score tiles per shared LDS stage (= per iteration): two while the registers allow it
+__host__ __device__ constexpr int pf_tiles(int head) { return head <= 128 ? 2 : 1; }
 
 __host__ __device__ constexpr int pf_dp(int head) { return (head + 31) / 32 * 32; }
 __host__ __device__ constexpr int pf_vstride(int head) {          // bytes per V row in LDS
@@ -64,9 +72,9 @@ __host__ __device__ constexpr int pf_vstride(int head) {          // bytes per V
 __host__ __device__ constexpr int pf_kstride(int head) {          // bytes per K row in LDS: 16 rows on 64 distinct banks
   return head * 2 + 16;
 }
-constexpr int kPfBufs = 3;                           // LDS stages: one in use, one landing, one free
+constexpr int kPfBufs = 2;                           // LDS stages: one in use, one landing
 __host__ __device__ constexpr int pf_lds_bytes(int head) {        // kPfBufs stages of a K and a V image
-  return kPfBufs * kPfStage * (pf_kstride(head) + pf_vstride(head));
+  return kPfBufs * pf_tiles(head) * kPfKeys * (pf_kstride(head) + pf_vstride(head));
 }
 
 // Keys and values that are already in the paged cache (a shared prefix, or the earlier chunks of
@@ -90,6 +98,8 @@ prefill_attention_kernel(uint16_t* __restrict__ out, const uint16_t* __restrict_
                          int64_t v_stride, int64_t out_stride, int sliding_window, PfContext cx) {
   using M = Mfma<act_t>;
   using frag = typename M::frag;
+  constexpr int NT = pf_tiles(HEAD);                 // score tiles per stage
+  constexpr int kPfStage = NT * kPfKeys;             // keys per stage
   constexpr int KS = HEAD / 16;                      // k-steps of the Q.K product
   constexpr int DP = pf_dp(HEAD);
   constexpr int DB = DP / 32;                        // 32-row blocks of O^T
@@ -157,35 +167,58 @@ prefill_attention_kernel(uint16_t* __restrict__ out, const uint16_t* __restrict_
   // probability is one v_exp_f32.  Online-softmax update shared by both phases: `s` holds the
   // masked, scaled scores of 32 keys.
   const float scale2 = scale * 1.4426950408889634f, slope2 = slope * 1.4426950408889634f;
-  frag pf[2];
-  auto softmax_step = [&](f32x16& s) {
+  // Online-softmax update over NT score tiles (32 keys each), in parts.  tile_max: the tiles' maximum
+  // joined with the running one.  wants_rescale / rescale: the output accumulator and the running sum
+  // are referred to a new maximum only when some lane's has grown by more than 2^8 since they last
+  // were; until then the probabilities are taken against that older maximum and may exceed 1 by up to
+  // that factor, which the fp32 sums and the 16-bit fragments hold without loss (the common factor
+  // cancels in the final division).  softmax_exp: the probabilities against `m_ref()`, as B operands
+  // of the P.V products (two 16-key fragments per tile), and their sum.
+  auto tile_max = [&](auto NTC, const f32x16* s) {
+    constexpr int NTS = decltype(NTC)::value;
     float m_tile = -INFINITY;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) m_tile = fmaxf(m_tile, s[r]);
+    for (int u = 0; u < NTS; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) m_tile = fmaxf(m_tile, s[u][r]);
     m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 32, 64));
-    const float m_new = fmaxf(m_run, m_tile);
-    // a query row beyond the sequence (or a fully masked window tile) keeps m at -inf: use 0
-    const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
-    float psum = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float p = __builtin_amdgcn_exp2f(s[r] - m_safe);
-      const auto pr = M::cvt(p);                     // rounded to the activation dtype
-      psum += p;
-      pf[r >> 3][r & 7] = pr;
-    }
-    // the running maximum rarely moves after the first tiles: rescale only when some lane's did
-    if (__builtin_amdgcn_ballot_w64(m_new != m_run) != 0) {
-      const float alpha = __builtin_amdgcn_exp2f(m_run - m_safe);
-      l_part *= alpha;
-#pragma unroll
-      for (int b = 0; b < DB; ++b)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[b][r] *= alpha;
-      m_run = m_new;
-    }
-    l_part += psum;
+    return fmaxf(m_run, m_tile);
   };
+  auto wants_rescale = [&](float m_new) { return __builtin_amdgcn_ballot_w64(m_new > m_run + 8.0f) != 0; };
+  auto rescale = [&](float m_new) {
+    const float alpha = __builtin_amdgcn_exp2f(m_run - ((m_new == -INFINITY) ? 0.f : m_new));
+    l_part *= alpha;
+#pragma unroll
+    for (int b = 0; b < DB; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[b][r] *= alpha;
+    m_run = m_new;
+  };
+  // a query row beyond the sequence (or a fully masked window tile) keeps m at -inf: use 0
+  auto m_ref = [&]() { return (m_run == -INFINITY) ? 0.f : m_run; };
+  auto softmax_exp = [&](auto NTC, const f32x16* s, float m_safe, frag* pf) {
+    constexpr int NTS = decltype(NTC)::value;
+    using f32x2 = __attribute__((ext_vector_type(2))) float;
+    const f32x2 m2 = {m_safe, m_safe};
+    f32x2 psum = {0.f, 0.f};                         // (pairs: the subtractions and the sums are packed instructions)
+#pragma unroll
+    for (int u = 0; u < NTS; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const f32x2 d = f32x2{s[u][r], s[u][r + 1]} - m2;
+        const f32x2 p = {__builtin_amdgcn_exp2f(d.x), __builtin_amdgcn_exp2f(d.y)};
+        psum += p;
+        pf[2 * u + (r >> 3)][r & 7] = M::cvt(p.x);   // rounded to the activation dtype
+        pf[2 * u + (r >> 3)][(r & 7) + 1] = M::cvt(p.y);
+      }
+    l_part += psum.x + psum.y;
+  };
+  auto softmax_step = [&](auto NTC, const f32x16* s, frag* pf) {
+    const float m_new = tile_max(NTC, s);
+    if (wants_rescale(m_new)) rescale(m_new);
+    softmax_exp(NTC, s, m_ref(), pf);
+  };
+  using One = std::integral_constant<int, 1>;
 
   if (CTX && active) {
     // ---- phase 1: the cached context.  Both operands come straight from the cache layouts: 8
@@ -250,7 +283,8 @@ prefill_attention_kernel(uint16_t* __restrict__ out, const uint16_t* __restrict_
           s[r] = ok ? x : -INFINITY;
         }
       }
-      softmax_step(s);
+      frag pf[2];
+      softmax_step(One{}, &s, pf);
 #pragma unroll
       for (int st = 0; st < 2; ++st)
 #pragma unroll
@@ -277,17 +311,32 @@ prefill_attention_kernel(uint16_t* __restrict__ out, const uint16_t* __restrict_
   // (native vectors: arrays of HIP's uint4 struct, assigned under a condition, are kept in scratch
   //  memory by the compiler)
   u32x4 kreg[LOADS], vreg[LOADS];
+  // K and V rows of this (sequence, kv head) through buffer loads: a lane's byte offset inside a stage is
+  // fixed, a stage adds a uniform amount, and rows past the end of the sequence are out of the
+  // descriptor's range and read as zero (no clamping, no 64-bit address arithmetic in the loop)
+  const auto k_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint16_t*>(k + row0 * k_stride + (int64_t)kv_head * HEAD), 0,
+      (int)(uint32_t)(((int64_t)(seq_len - 1) * k_stride + HEAD) * 2), 0x00020000);
+  const auto v_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint16_t*>(v + row0 * v_stride + (int64_t)kv_head * HEAD), 0,
+      (int)(uint32_t)(((int64_t)(seq_len - 1) * v_stride + HEAD) * 2), 0x00020000);
+  uint32_t koff[LOADS], voff[LOADS];
+#pragma unroll
+  for (int it = 0; it < LOADS; ++it) {
+    const int c = it * kPfWaves * 64 + tid;
+    const int key = c / CPR, ch = c - key * CPR;
+    koff[it] = (uint32_t)(key * k_stride + ch * 8) * 2u;
+    voff[it] = (uint32_t)(key * v_stride + ch * 8) * 2u;
+  }
   // (compile-time slot indices and no early exit from the loop body: the staging registers must
   // not end up addressed through memory)
   auto fetch = [&](int t0) {
+    const uint32_t k_stage = (uint32_t)t0 * (uint32_t)k_stride * 2u, v_stage = (uint32_t)t0 * (uint32_t)v_stride * 2u;
     static_for<LOADS>([&](auto IT) {
       constexpr int it = decltype(IT)::value;
-      const int c = it * kPfWaves * 64 + tid;
-      if (CHUNKS % (kPfWaves * 64) == 0 || c < CHUNKS) {
-        const int key = c / CPR, ch = c - key * CPR;
-        const int64_t row = row0 + min(t0 + key, seq_len - 1);
-        kreg[it] = *reinterpret_cast<const u32x4*>(k + row * k_stride + (int64_t)kv_head * HEAD + ch * 8);
-        vreg[it] = *reinterpret_cast<const u32x4*>(v + row * v_stride + (int64_t)kv_head * HEAD + ch * 8);
+      if (CHUNKS % (kPfWaves * 64) == 0 || it * kPfWaves * 64 + tid < CHUNKS) {
+        kreg[it] = __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, (int)(koff[it] + k_stage), 0, 0);
+        vreg[it] = __builtin_amdgcn_raw_buffer_load_b128(v_rsrc, (int)(voff[it] + v_stage), 0, 0);
       }
     });
   };
@@ -303,94 +352,108 @@ prefill_attention_kernel(uint16_t* __restrict__ out, const uint16_t* __restrict_
     });
   };
 
-  // Software pipeline over stages (one stage = one score tile of 32 keys), three LDS buffers:
-  //   iteration t:  stage t+2 registers -> LDS | stage t+3 global -> registers |
-  //                 S(t+1) = K(t+1) . Q^T on the matrix cores, issued BEFORE the vector work of
-  //                 softmax(S(t)), so the two overlap inside the wave | O += V(t)^T . P(t)^T | barrier
-  static_assert(kPfStage == kPfKeys, "one score tile per stage");
+  // Stages of NT score tiles (64 keys up to head size 128), two LDS buffers:
+  //   iteration t:  stage t+1 registers -> LDS (the buffer that iteration t-1 read, released by its
+  //                 barrier) | stage t+2 global -> registers | both score tiles of stage t: S = K . Q^T,
+  //                 mask, one softmax update, O += V^T . P^T | barrier
   const int stages = (wg_end - wg_begin + kPfStage - 1) / kPfStage;
-  auto needs = [&](int t) {
-    const int k0 = wg_begin + t * kPfStage;
-    return active && k0 < k_end && k0 + kPfKeys > k_begin;
-  };
-  auto qk = [&](int buf) {
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    const char* kb = k_img + buf * kPfStage * KSTRIDE + k_off;
-#pragma unroll
-    for (int h0 = 0; h0 < KS; h0 += 4) {              // fragments in groups of 4: fewer live registers
-      frag kf[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-        if (h0 + i < KS) kf[i] = *reinterpret_cast<const frag*>(kb + 32 * (h0 + i));
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-        if (h0 + i < KS) acc = M::run(kf[i], qf[h0 + i], acc);
-    }
-    return acc;
-  };
+  auto needs = [&](int k0) { return active && k0 < k_end && k0 + kPfKeys > k_begin; };
 
   fetch(wg_begin);
   commit(0);
-  if (stages > 1) {
-    fetch(wg_begin + kPfStage);
-    commit(1);
-  }
-  if (stages > 2) fetch(wg_begin + 2 * kPfStage);
+  if (stages > 1) fetch(wg_begin + kPfStage);
   __syncthreads();
-  f32x16 s_cur, s_next;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) s_cur[r] = s_next[r] = 0.f;
-  if (needs(0)) s_cur = qk(0);
   int buf = 0;
-  for (int t = 0; t < stages; ++t) {
+  for (int t = 0; t < stages; ++t) {                   // stages is workgroup-uniform: every wave meets every barrier
     const int k0 = wg_begin + t * kPfStage;
-    const int b1 = buf == 2 ? 0 : buf + 1, b2 = b1 == 2 ? 0 : b1 + 1;
-    if (t + 2 < stages) commit(b2);                   // that buffer was last read before the previous barrier
-    if (t + 3 < stages) fetch(k0 + 3 * kPfStage);
-    if (t + 1 < stages && needs(t + 1)) s_next = qk(b1);
-    if (needs(t)) {
-      f32x16& s = s_cur;
-      // ---- mask, online softmax (this lane: query q_idx, keys k0 + (r&3) + 8*(r>>2) + 4*half)
-      const bool need_mask = (k0 + kPfKeys - 1 > q0) || (sliding_window > 0);
-      if (!need_mask && slope == 0.f) {                            // wave-uniform: a tile below the diagonal
+    if (t + 1 < stages) commit(buf ^ 1);
+    if (t + 2 < stages) fetch(k0 + 2 * kPfStage);
+    bool any = false;                                              // wave-uniform
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s[r] *= scale2;
-      } else {
+    for (int u = 0; u < NT; ++u) any = any || needs(k0 + u * kPfKeys);
+    if (any) {
+      // (a tile this wave does not need -- above the diagonal, outside the window -- is computed and
+      // masked: keeping it out would make the fragment registers conditionally assigned, which the
+      // compiler answers with scratch memory)
+      const char* kb = k_img + buf * kPfStage * KSTRIDE + k_off;
+      const char* vb = v_img + buf * kPfStage * VSTRIDE + tr_off;
+      // S^T = K . Q^T of tile u
+      auto qk_tile = [&](int u) {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int h0 = 0; h0 < KS; h0 += 4) {          // fragments in groups of 4: fewer live registers
+          frag kf[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (h0 + i < KS) kf[i] = *reinterpret_cast<const frag*>(kb + u * kPfKeys * KSTRIDE + 32 * (h0 + i));
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (h0 + i < KS) acc = M::run(kf[i], qf[h0 + i], acc);
+        }
+        return acc;
+      };
+      // scale and mask (this lane: query q_idx, keys kt + (r&3) + 8*(r>>2) + 4*half)
+      auto mask_scale = [&](f32x16& sc, int kt) {
+        if (!needs(kt)) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) sc[r] = -INFINITY;
+          return;
+        }
+        const bool need_mask = (kt + kPfKeys - 1 > q0) || (sliding_window > 0);
+        if (!need_mask && slope == 0.f) {                          // wave-uniform: a tile below the diagonal
+#pragma unroll
+          for (int r = 0; r < 16; ++r) sc[r] *= scale2;
+          return;
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-          float x = s[r] * scale2;
+          const int key = kt + (r & 3) + 8 * (r >> 2) + 4 * half;
+          float x = sc[r] * scale2;
           if (slope != 0.f) x += slope2 * (float)(key - q_idx);
           if (need_mask) {
             bool ok = key <= q_idx;
             if (sliding_window > 0) ok = ok && (q_idx - key < sliding_window);
             x = ok ? x : -INFINITY;
           }
-          s[r] = x;
+          sc[r] = x;
         }
-      }
-      softmax_step(s);
-      // ---- O^T += V^T . P^T ; A operand element j <-> key 16*st + 8*(j>>2) + 4*half + (j&3)
-      const char* vb = v_img + buf * kPfStage * VSTRIDE + tr_off;
+      };
+      // O^T += V^T . P^T of tile u; A operand element j <-> key 16*st + 8*(j>>2) + 4*half + (j&3)
+      auto pv_tile = [&](int u, const frag* pt) {
 #pragma unroll
-      for (int st = 0; st < 2; ++st) {
+        for (int st = 0; st < 2; ++st) {
 #pragma unroll
-        for (int b = 0; b < DB; ++b) {
-          const char* base = vb + (16 * st) * VSTRIDE + b * 64;
-          const i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_i16x4_ptr)(base));
-          const i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_i16x4_ptr)(base + 8 * VSTRIDE));
-          union { struct { i16x4 a, b; } p; frag f; } vf;
-          vf.p.a = lo;
-          vf.p.b = hi;
-          o[b] = M::run(vf.f, pf[st], o[b]);
+          for (int b = 0; b < DB; ++b) {
+            const char* base = vb + (32 * u + 16 * st) * VSTRIDE + b * 64;
+            const i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_i16x4_ptr)(base));
+            const i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_i16x4_ptr)(base + 8 * VSTRIDE));
+            union { struct { i16x4 a, b; } p; frag f; } vf;
+            vf.p.a = lo;
+            vf.p.b = hi;
+            o[b] = M::run(vf.f, pt[st], o[b]);
+          }
         }
-      }
+      };
+      // Both tiles' scores first (two independent chains of matrix products), ONE softmax update over
+      // the 32 scores per lane (one maximum exchange, one rescale decision), then both tiles' P.V
+      // products, among which the compiler spreads the exponentials.  (Tried and dropped: exp(a)
+      // beside S_b and exp(b) beside P_a.V with an update per tile -- the rescale between the tiles
+      // must then see tile a's products, and the two code arms that takes cost more register copies
+      // than the overlap saves: the two waves of a SIMD already fill each other's gaps.)
+      f32x16 sv[NT];
+#pragma unroll
+      for (int u = 0; u < NT; ++u) sv[u] = qk_tile(u);
+#pragma unroll
+      for (int u = 0; u < NT; ++u) mask_scale(sv[u], k0 + u * kPfKeys);
+      frag pt[2 * NT];
+      softmax_step(std::integral_constant<int, NT>{}, sv, pt);
+#pragma unroll
+      for (int u = 0; u < NT; ++u) pv_tile(u, pt + 2 * u);
     }
     __syncthreads();
-    s_cur = s_next;
-    buf = b1;
+    buf ^= 1;
   }
   if (!active) return;
 
@@ -448,6 +511,9 @@ int prefill_entry(void* out, const void* query, const void* key, const void* val
   SW_CHECK_ARG(act_dtype == SW_F16 || act_dtype == SW_BF16,
                "Unsupported data type for prefill attention: %d (float16 / bfloat16 only)", act_dtype);
   SW_CHECK_ARG(num_seqs <= 65535 && num_heads <= 65535, "prefill_attention: grid too large");
+  SW_CHECK_ARG((int64_t)max_seq_len * std::max(k_stride, v_stride) * 2 < ((int64_t)1 << 32),
+               "prefill_attention: a sequence's keys / values span %lld bytes, more than 32-bit offsets address",
+               (long long)max_seq_len * (long long)std::max(k_stride, v_stride) * 2);
   SW_CHECK_ARG(q_stride % 8 == 0 && k_stride % 8 == 0 && v_stride % 8 == 0 && out_stride % 4 == 0 &&
                    reinterpret_cast<uintptr_t>(query) % 16 == 0 && reinterpret_cast<uintptr_t>(key) % 16 == 0 &&
                    reinterpret_cast<uintptr_t>(value) % 16 == 0 && reinterpret_cast<uintptr_t>(out) % 8 == 0,
