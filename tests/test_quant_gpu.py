@@ -85,6 +85,10 @@ GEMM_SHAPES = [          # (M, K, N, group)
     (1, 128, 128, 128), (1, 2560, 5120, 128), (3, 256, 136, 32), (7, 1024, 520, 64), (8, 5120, 7680, 128),
     (16, 512, 384, 512), (32, 6912, 1024, 128), (33, 512, 256, 128), (50, 1024, 384, 64), (64, 2048, 1000, 128),
     (100, 512, 264, 32), (200, 1024, 512, 128), (5, 96, 64, 32), (40, 160, 72, 32), (130, 384, 200, 64),
+    # the 128-row tile kernel: ragged rows and columns, one and two row tiles, groups of 64 / 128 / 256 / all of k,
+    # k split across workgroups (few column tiles) and not (many), and the wide-matrix case from 97 rows on
+    (129, 512, 136, 64), (256, 1024, 264, 128), (255, 768, 1024, 256), (192, 2560, 320, 64), (250, 1280, 72, 1280),
+    (160, 256, 3200, 128), (100, 256, 12288, 128),
 ]
 
 
@@ -99,7 +103,8 @@ def test_gptq_gemm_shuffled(m, k, n, group):
     _close(got, quant.gptq_gemm(a, w, qzeros, scales, None, True))
 
 
-@pytest.mark.parametrize("m,k,n,group", [(1, 512, 256, 128), (9, 1024, 520, 64), (48, 512, 128, 32), (70, 512, 136, 128)])
+@pytest.mark.parametrize("m,k,n,group", [(1, 512, 256, 128), (9, 1024, 520, 64), (48, 512, 128, 32), (70, 512, 136, 128),
+                                         (140, 512, 264, 128)])
 def test_gptq_gemm_act_order(m, k, n, group):
     from splitwise_amd import _C
     qweight, qzeros, scales, g_idx = _gptq_case(k, n, group, 3 * m + k, act_order=True)

@@ -97,6 +97,31 @@ __device__ __forceinline__ f16x8 gptq_dequant8(uint32_t w, const GptqCol& col) {
   return r.f;
 }
 
+// The same with the masks and the exponent pattern held in registers (lo, hi: scalar; magic: vector), which lets
+// each (w & mask) | magic be ONE v_and_or_b32: with literal constants the compiler emits an AND and an OR.
+struct DequantRegs { uint32_t lo, hi, magic; };
+__device__ __forceinline__ DequantRegs dequant_regs() {
+  DequantRegs k{0x000f000fu, 0x00f000f0u, kMagic};
+  asm volatile("" : "+s"(k.lo), "+s"(k.hi));
+  asm volatile("" : "+v"(k.magic));
+  return k;
+}
+__device__ __forceinline__ f16x8 gptq_dequant8(uint32_t w, const GptqCol& col, const DequantRegs& k) {
+  const h2 y16 = splat((_Float16)0.0625f);
+  const h2 q0 = as_h2((w & k.lo) | k.magic);
+  const h2 q1 = as_h2((w & k.hi) | k.magic);
+  w >>= 8;
+  const h2 q2 = as_h2((w & k.lo) | k.magic);
+  const h2 q3 = as_h2((w & k.hi) | k.magic);
+  const h2 d0 = (q0 + col.z1) * col.s;
+  const h2 d1 = (q1 * y16 + col.z16) * col.s;
+  const h2 d2 = (q2 + col.z1) * col.s;
+  const h2 d3 = (q3 * y16 + col.z16) * col.s;
+  union { uint32_t u[4]; f16x8 f; } r;
+  r.u[0] = as_u32(d0); r.u[1] = as_u32(d1); r.u[2] = as_u32(d2); r.u[3] = as_u32(d3);
+  return r.f;
+}
+
 __device__ __forceinline__ uint32_t shuffle_nibbles(uint32_t qa) {
   uint32_t qb = 0;
 #pragma unroll
@@ -245,45 +270,50 @@ __device__ __forceinline__ void combine_and_store(ValOf val_of, RowOf row_of, bo
     last = *s_last != 0;
   }
   if (!last) return;
-  float v[ROWS][CP];
+  // the final sum, RB rows at a time (all of a thread's loads of one split and block are issued before the first is used)
+  constexpr int RB = ROWS > 32 ? 16 : ROWS;
+  static_assert(ROWS % RB == 0, "row blocks must tile the thread's rows");
 #pragma unroll
-  for (int i = 0; i < ROWS; ++i)
+  for (int b0 = 0; b0 < ROWS; b0 += RB) {
+    float v[RB][CP];
 #pragma unroll
-    for (int cc = 0; cc < CP; ++cc) v[i][cc] = ksplit > 1 ? 0.f : val_of(i, cc);
-  if (ksplit > 1) {
-    for (int z = 0; z < ksplit; ++z) {                  // fixed order: reproducible
-      // all of this thread's loads of one split are issued before the first is used
-      float p[ROWS][CP];
+    for (int i = 0; i < RB; ++i)
 #pragma unroll
-      for (int i = 0; i < ROWS; ++i) {
-        const int m = row_of(i);
-        const bool ok = m < M && col_ok;
-        const int off = ok ? (int)((((size_t)z * M + m) * N + ncol) * 4) : 0;
-        if constexpr (CP == 4) {
-          const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, kAuxSystem);
-          p[i][0] = __uint_as_float(q.x); p[i][1] = __uint_as_float(q.y);
-          p[i][2] = __uint_as_float(q.z); p[i][3] = __uint_as_float(q.w);
-        } else {
-          const u32x2 q = __builtin_amdgcn_raw_buffer_load_b64(rsrc, off, 0, kAuxSystem);
-          p[i][0] = __uint_as_float(q.x); p[i][1] = __uint_as_float(q.y);
+      for (int cc = 0; cc < CP; ++cc) v[i][cc] = ksplit > 1 ? 0.f : val_of(b0 + i, cc);
+    if (ksplit > 1) {
+      for (int z = 0; z < ksplit; ++z) {                  // fixed order: reproducible
+        float p[RB][CP];
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+          const int m = row_of(b0 + i);
+          const bool ok = m < M && col_ok;
+          const int off = ok ? (int)((((size_t)z * M + m) * N + ncol) * 4) : 0;
+          if constexpr (CP == 4) {
+            const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, kAuxSystem);
+            p[i][0] = __uint_as_float(q.x); p[i][1] = __uint_as_float(q.y);
+            p[i][2] = __uint_as_float(q.z); p[i][3] = __uint_as_float(q.w);
+          } else {
+            const u32x2 q = __builtin_amdgcn_raw_buffer_load_b64(rsrc, off, 0, kAuxSystem);
+            p[i][0] = __uint_as_float(q.x); p[i][1] = __uint_as_float(q.y);
+          }
         }
+#pragma unroll
+        for (int i = 0; i < RB; ++i)
+#pragma unroll
+          for (int cc = 0; cc < CP; ++cc) v[i][cc] += p[i][cc];
       }
-#pragma unroll
-      for (int i = 0; i < ROWS; ++i)
-#pragma unroll
-        for (int cc = 0; cc < CP; ++cc) v[i][cc] += p[i][cc];
     }
-  }
 #pragma unroll
-  for (int i = 0; i < ROWS; ++i) {
-    const int m = row_of(i);
-    if (m >= M || !col_ok) continue;
-    uint32_t o[CP / 2];
+    for (int i = 0; i < RB; ++i) {
+      const int m = row_of(b0 + i);
+      if (m >= M || !col_ok) continue;
+      uint32_t o[CP / 2];
 #pragma unroll
-    for (int cc = 0; cc < CP; cc += 2)
-      o[cc / 2] = (uint32_t)float_to_f16_bits(v[i][cc]) | ((uint32_t)float_to_f16_bits(v[i][cc + 1]) << 16);
-    if constexpr (CP == 4) *reinterpret_cast<uint2*>(c + (size_t)m * N + ncol) = make_uint2(o[0], o[1]);
-    else *reinterpret_cast<uint32_t*>(c + (size_t)m * N + ncol) = o[0];
+      for (int cc = 0; cc < CP; cc += 2)
+        o[cc / 2] = (uint32_t)float_to_f16_bits(v[i][cc]) | ((uint32_t)float_to_f16_bits(v[i][cc + 1]) << 16);
+      if constexpr (CP == 4) *reinterpret_cast<uint2*>(c + (size_t)m * N + ncol) = make_uint2(o[0], o[1]);
+      else *reinterpret_cast<uint32_t*>(c + (size_t)m * N + ncol) = o[0];
+    }
   }
   if (ksplit > 1 && threadIdx.x == 0)                    // ready for the next call
     __hip_atomic_store(&counters[tile], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -354,8 +384,8 @@ gptq_gemm_kwaves_kernel(uint16_t* __restrict__ c, const uint16_t* __restrict__ a
 constexpr int kChunkK = 256;                        // k per A chunk = 16 steps
 constexpr int kARow = kChunkK * 2 + 16;             // LDS bytes per A row; the pad keeps 16 rows on 64 distinct banks
 
-template <int MT, int CP, int CHUNK>
-__global__ void __launch_bounds__(kGemmWaves * 64)
+template <int MT, int CP, int CHUNK, int WAVES>
+__global__ void __launch_bounds__(WAVES * 64)
 gptq_gemm_tiled_kernel(uint16_t* __restrict__ c, const uint16_t* __restrict__ a, const uint32_t* __restrict__ qweight,
                        const uint32_t* __restrict__ qzeros, const uint16_t* __restrict__ scales, int M, int N, int K,
                        int group_size, int ksplit, int col_tiles, int row_tiles, int zoff, float* __restrict__ partials,
@@ -369,7 +399,7 @@ gptq_gemm_tiled_kernel(uint16_t* __restrict__ c, const uint16_t* __restrict__ a,
   constexpr int BM = 32 * MT;
   constexpr int SEGS = CHUNK / 8;                   // 16-byte pieces per A row of a chunk
   constexpr int PIECES = BM * SEGS;
-  constexpr int PPT = (PIECES + kGemmWaves * 64 - 1) / (kGemmWaves * 64);
+  constexpr int PPT = (PIECES + WAVES * 64 - 1) / (WAVES * 64);
   extern __shared__ __attribute__((aligned(16))) char a_lds[];   // 2 x BM x kARow
   __shared__ int s_last;
   const int tid = threadIdx.x;
@@ -386,7 +416,7 @@ gptq_gemm_tiled_kernel(uint16_t* __restrict__ c, const uint16_t* __restrict__ a,
   const int split = work % ksplit;                    // the k splits of a tile run side by side on one XCD: the last
   const int row_tile = (work / ksplit) % row_tiles;   // to arrive finds the others' partial tiles in that XCD's L2
   const int col_tile = work / (ksplit * row_tiles);
-  const int ncol = (col_tile * kGemmWaves + wave) * 32 * CP + CP * j;
+  const int ncol = (col_tile * WAVES + wave) * 32 * CP + CP * j;
   const bool col_ok = ncol < N;
   const int ncl = col_ok ? ncol : 0;
   const int m0 = row_tile * BM;
@@ -411,8 +441,8 @@ gptq_gemm_tiled_kernel(uint16_t* __restrict__ c, const uint16_t* __restrict__ a,
   auto a_fetch = [&](int chunk) {
     static_for<PPT>([&](auto Q) {
       constexpr int qi = decltype(Q)::value;
-      const int p = tid + qi * kGemmWaves * 64;
-      if (PIECES % (kGemmWaves * 64) == 0 || p < PIECES) {
+      const int p = tid + qi * WAVES * 64;
+      if (PIECES % (WAVES * 64) == 0 || p < PIECES) {
         const int row = p / SEGS, seg = p % SEGS;
         a_stage[qi] = *reinterpret_cast<const u32x4*>(a + (size_t)min(m0 + row, M - 1) * K + chunk * CHUNK + seg * 8);
       }
@@ -421,8 +451,8 @@ gptq_gemm_tiled_kernel(uint16_t* __restrict__ c, const uint16_t* __restrict__ a,
   auto a_commit = [&](int buf) {
     static_for<PPT>([&](auto Q) {
       constexpr int qi = decltype(Q)::value;
-      const int p = tid + qi * kGemmWaves * 64;
-      if (PIECES % (kGemmWaves * 64) == 0 || p < PIECES) {
+      const int p = tid + qi * WAVES * 64;
+      if (PIECES % (WAVES * 64) == 0 || p < PIECES) {
         const int row = p / SEGS, seg = p % SEGS;
         *reinterpret_cast<u32x4*>(a_lds + buf * BM * kARowC + row * kARowC + seg * 16) = a_stage[qi];
       }
@@ -500,6 +530,250 @@ gptq_gemm_tiled_kernel(uint16_t* __restrict__ c, const uint16_t* __restrict__ a,
   auto val_of = [&](int i, int cc) { return acc[i / 16][cc][i % 16]; };
   combine_and_store<CP, 16 * MT>(val_of, row_of, col_ok, ncol, c, M, N, ksplit, partials, counters,
                                  row_tile * col_tiles + col_tile, split, &s_last);
+}
+
+// Variant "128-row tiles" (rows of A in blocks of 128, groups that are multiples of the wave's k part): a workgroup
+// owns 128 rows x (8 / KQ) * 64 columns over its k range.  Its 8 waves are 8 / KQ column groups of 64 columns x KQ
+// k parts: in every chunk of KQ * SPW * 16 k of A (three buffers in LDS, one barrier per chunk) a wave multiplies its
+// SPW steps of 16 k, so one unpacked weight word feeds four matrix instructions, and the k parts meet once, through
+// LDS, at the end (the wave of k part q ends up with row blocks q * 4 / KQ ..).  The A pieces of chunk n+2 are
+// requested while chunk n is multiplied and written to LDS a whole chunk later; the weights run 8 steps ahead.  The
+// loop over a chunk has no branch in it: prefetches past the end of the k range re-read the last chunk instead.
+constexpr int kT128ARowPad = 16;                     // the pad keeps 16 rows on distinct bank groups
+template <int KQ, int SPW> constexpr int t128_chunk() { return KQ * SPW * 16; }
+template <int MT, int KQ, int SPW, int NBUF> constexpr int t128_lds() {
+  return NBUF * 32 * MT * (t128_chunk<KQ, SPW>() * 2 + kT128ARowPad);
+}
+
+template <int MT, int KQ, int CG, int SPW, int NBUF>
+__global__ void __launch_bounds__(KQ * CG * 64)
+gptq_gemm_tile128_kernel(uint16_t* __restrict__ c, const uint16_t* __restrict__ a, const uint32_t* __restrict__ qweight,
+                         const uint32_t* __restrict__ qzeros, const uint16_t* __restrict__ scales, int M, int N, int K,
+                         int group_size, int ksplit, int col_tiles, int row_tiles, int zoff,
+                         float* __restrict__ partials, int32_t* __restrict__ counters) {
+  constexpr int CP = 2;                               // columns per lane
+  constexpr int NT = KQ * CG * 64;                    // threads
+  constexpr int BM = 32 * MT;                         // rows of A per workgroup
+  constexpr int BPO = MT / KQ;                        // row blocks a wave keeps at the end
+  constexpr int RD = 8 / SPW;                         // chunks of weights in flight (8 steps)
+  constexpr int CHUNK = t128_chunk<KQ, SPW>();
+  constexpr int AROW = CHUNK * 2 + kT128ARowPad;      // LDS bytes per A row
+  constexpr int ABUF = BM * AROW;
+  constexpr int SEGS = CHUNK / 8;                     // 16-byte pieces per A row
+  constexpr int PPT = BM * SEGS / NT;                 // pieces per thread and chunk
+  constexpr int PH = PPT / 2;                         // moved in two halves, at the top and in the middle of a chunk
+  static_assert(PPT % 2 == 0 && BPO >= 1, "tile shape");
+  extern __shared__ __attribute__((aligned(16))) char a_lds[];
+  __shared__ int s_last;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cg = wave % CG, kq = wave / CG;
+  const int j = lane & 31, half = lane >> 5;
+  // workgroup order as in the tiled kernel: the k splits and row tiles of a column tile share an XCD
+  const int total = col_tiles * row_tiles * ksplit;
+  const int per_xcd = (total + 7) / 8;
+  const int work = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+  if (work >= total) return;
+  const int split = work % ksplit;
+  const int row_tile = (work / ksplit) % row_tiles;
+  const int col_tile = work / (ksplit * row_tiles);
+  const int ncol = (col_tile * CG + cg) * 64 + CP * j;
+  const bool col_ok = ncol < N;
+  const int ncl = col_ok ? ncol : 0;
+  const int m0 = row_tile * BM;
+  const int chunks = K / CHUNK;
+  const int c_begin = (int)((int64_t)chunks * split / ksplit), c_end = (int)((int64_t)chunks * (split + 1) / ksplit);
+
+  f32x16 acc[MT][CP];
+#pragma unroll
+  for (int t = 0; t < MT; ++t)
+#pragma unroll
+    for (int cc = 0; cc < CP; ++cc)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][cc][r] = 0.f;
+  const DequantRegs dq = dequant_regs();
+
+  // ---- A staging: 128 rows x SEGS pieces of 16 bytes per chunk, PPT per thread in two halves
+  constexpr int SETS = NBUF == 3 ? 2 : 1;             // register sets for pieces in flight
+  u32x4 a_stage[SETS][PH];
+  auto a_fetch = [&](auto HALF, int chunk) {
+    constexpr int hf = decltype(HALF)::value;
+    const int ch = min(chunk, c_end - 1);
+    static_for<PH>([&](auto Q) {
+      constexpr int qi = decltype(Q)::value;
+      const int p = tid + (hf * PH + qi) * NT;
+      const int row = p / SEGS, seg = p % SEGS;
+      a_stage[hf % SETS][qi] =
+          *reinterpret_cast<const u32x4*>(a + (size_t)min(m0 + row, M - 1) * K + ch * CHUNK + seg * 8);
+    });
+  };
+  auto a_commit = [&](auto HALF, int buf_off) {
+    constexpr int hf = decltype(HALF)::value;
+    static_for<PH>([&](auto Q) {
+      constexpr int qi = decltype(Q)::value;
+      const int p = tid + (hf * PH + qi) * NT;
+      const int row = p / SEGS, seg = p % SEGS;
+      *reinterpret_cast<u32x4*>(a_lds + buf_off + row * AROW + seg * 16) = a_stage[hf % SETS][qi];
+    });
+  };
+
+  // ---- weights: RD chunks (8 steps of this wave) in flight, slot = chunk index mod RD
+  const uint32_t* wp = qweight + (size_t)half * N + ncl;
+  const int zshift = 4 * (ncl & 7);
+  uint2 wq[RD][SPW];
+  uint32_t zq[RD], sq[RD];
+  auto w_load = [&](auto SLOT, auto STEP, int chunk) {
+    constexpr int slot = decltype(SLOT)::value, i = decltype(STEP)::value;
+    const int s = (min(chunk, c_end - 1) * KQ + kq) * SPW + i;
+    wq[slot][i] = *reinterpret_cast<const uint2*>(wp + (size_t)(2 * s) * N);
+  };
+  auto g_load = [&](auto SLOT, int chunk) {
+    constexpr int slot = decltype(SLOT)::value;
+    const int g = (min(chunk, c_end - 1) * KQ + kq) * (SPW * 16) / group_size;
+    zq[slot] = qzeros[(size_t)g * (N / 8) + ncl / 8];
+    sq[slot] = *reinterpret_cast<const uint32_t*>(scales + (size_t)g * N + ncl);
+  };
+  using H0 = std::integral_constant<int, 0>;
+  using H1 = std::integral_constant<int, 1>;
+  // One chunk = 2 * SPW half steps (step i, column c of the lane's two).  The instruction order is pinned: the weight
+  // word of half step h+1 is unpacked, and the A fragments of step i+1 are read, between the four matrix instructions
+  // of half step h, so the matrix pipe never waits for the vector pipe inside a chunk.
+  auto body = [&](auto SLOT, int chunk, int buf_cur, int buf_next) {
+    constexpr int slot = decltype(SLOT)::value;
+    // Three buffers: the pieces of chunk + 2 are requested while those of chunk + 1, requested a chunk ago, go into
+    // buf_next (nobody reads it any more after this barrier).  Two buffers: a thread holds one half of a chunk at a
+    // time, so a half is written half a chunk after it was requested.
+    if constexpr (NBUF == 2) a_commit(H1{}, buf_cur * ABUF);
+    __syncthreads();
+    if constexpr (NBUF == 3) a_commit(H0{}, buf_next * ABUF);
+    a_fetch(H0{}, chunk + (NBUF == 3 ? 2 : 1));
+    const uint32_t z = zq[slot] >> zshift;
+    GptqCol col[CP];
+    col[0] = gptq_col((z & 0xfu) + zoff, (uint16_t)(sq[slot] & 0xffffu));
+    col[1] = gptq_col(((z >> 4) & 0xfu) + zoff, (uint16_t)(sq[slot] >> 16));
+    g_load(SLOT, chunk + RD);
+    const char* a_buf = a_lds + buf_cur * ABUF + j * AROW + (kq * SPW) * 32 + half * 16;
+    f16x8 af[2][MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) af[0][t] = *reinterpret_cast<const f16x8*>(a_buf + 32 * t * AROW);
+    f16x8 b_next = gptq_dequant8(wq[slot][0].x, col[0], dq);
+    __builtin_amdgcn_sched_barrier(0);
+    static_for<2 * SPW>([&](auto H) {
+      constexpr int h = decltype(H)::value, i = h / 2, cc = h % 2;
+      const f16x8 b_cur = b_next;
+      if constexpr (h + 1 < 2 * SPW) {
+        constexpr int i2 = (h + 1) / 2, c2 = (h + 1) % 2;
+        b_next = gptq_dequant8(c2 ? wq[slot][i2].y : wq[slot][i2].x, col[c2], dq);
+      }
+      if constexpr (cc == 0 && i + 1 < SPW) {
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+          af[(i + 1) & 1][t] = *reinterpret_cast<const f16x8*>(a_buf + 32 * t * AROW + (i + 1) * 32);
+      }
+      if constexpr (cc == 1) w_load(SLOT, std::integral_constant<int, i>{}, chunk + RD);
+#pragma unroll
+      for (int t = 0; t < MT; ++t)
+        acc[t][cc] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i & 1][t], b_cur, acc[t][cc], 0, 0, 0);
+      // 0x8 matrix, 0x2 vector ALU, 0x100 LDS read, 0x20 memory read
+      constexpr int VPM = MT >= 8 ? 2 : 4;              // vector instructions placed after each matrix instruction
+      if constexpr (cc == 0) {
+        static_for<MT>([&](auto) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        });
+      } else {
+        static_for<MT>([&](auto) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);
+        });
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (h == SPW - 1) {                     // mid chunk: the second half of chunk + 1 goes in, the second
+        if constexpr (NBUF == 3) a_commit(H1{}, buf_next * ABUF);
+        else a_commit(H0{}, buf_next * ABUF);
+        a_fetch(H1{}, chunk + (NBUF == 3 ? 2 : 1));
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    });
+  };
+
+  if (c_begin < c_end) {
+    static_for<RD>([&](auto SLOT) {
+      static_for<SPW>([&](auto STEP) { w_load(SLOT, STEP, c_begin + decltype(SLOT)::value); });
+      g_load(SLOT, c_begin + decltype(SLOT)::value);
+    });
+    if constexpr (NBUF == 3) {
+      a_fetch(H0{}, c_begin);
+      a_fetch(H1{}, c_begin);
+      a_commit(H0{}, 0);
+      a_commit(H1{}, 0);
+      a_fetch(H0{}, c_begin + 1);
+      a_fetch(H1{}, c_begin + 1);
+    } else {
+      a_fetch(H0{}, c_begin);
+      a_commit(H0{}, 0);
+      a_fetch(H1{}, c_begin);
+    }
+    int buf = 0;
+    for (int chunk = c_begin; chunk < c_end; chunk += RD) {
+      static_for<RD>([&](auto SLOT) {
+        constexpr int u = decltype(SLOT)::value;
+        if (u == 0 || chunk + u < c_end) {
+          const int nxt = buf == NBUF - 1 ? 0 : buf + 1;
+          body(SLOT, chunk + u, buf, nxt);
+          buf = nxt;
+        }
+      });
+    }
+  }
+
+  // ---- the k parts meet: the wave of k part q keeps row blocks q * BPO .. + BPO - 1 and is sent the other parts'
+  // sums of them through LDS, one block per pass.
+  // (selects between VALUES of fixed accumulator elements: a branch or a conditional expression between two
+  // elements becomes a select between their addresses, which keeps the whole accumulator array in scratch memory)
+  float* red = reinterpret_cast<float*>(a_lds);
+  auto block_of = [&](int q, auto TT, int cc, int r) {  // acc[q * BPO + tt][cc][r] for a wave-uniform runtime q
+    constexpr int tt = decltype(TT)::value;
+    float v = acc[tt][cc][r];
+#pragma unroll
+    for (int o = 1; o < KQ; ++o) { const float w = acc[o * BPO + tt][cc][r]; v = q == o ? w : v; }
+    return v;
+  };
+  static_for<(KQ - 1) * BPO>([&](auto P) {
+    constexpr int d = 1 + decltype(P)::value / BPO, tt = decltype(P)::value % BPO;
+    const int to = (kq + d) % KQ, from = (kq + KQ - d) % KQ;
+    __syncthreads();
+#pragma unroll
+    for (int cc = 0; cc < CP; ++cc)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        red[((wave * 32 + cc * 16 + r) << 6) + lane] = block_of(to, std::integral_constant<int, tt>{}, cc, r);
+    __syncthreads();
+    const int src_wave = from * CG + cg;
+#pragma unroll
+    for (int cc = 0; cc < CP; ++cc)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float v = red[((src_wave * 32 + cc * 16 + r) << 6) + lane];
+#pragma unroll
+        for (int o = 0; o < KQ; ++o) acc[o * BPO + tt][cc][r] += kq == o ? v : 0.f;   // only the kept block changes
+      }
+  });
+  auto row_of = [&](int i) {
+    const int t = i / 16, r = i % 16;
+    return m0 + 32 * (kq * BPO + t) + 8 * (r >> 2) + 4 * half + (r & 3);
+  };
+  auto val_of = [&](int i, int cc) {                    // acc[kq * BPO + i / 16][cc][i % 16], by value selects
+    float v = acc[i / 16][cc][i % 16];
+#pragma unroll
+    for (int o = 1; o < KQ; ++o) { const float w = acc[o * BPO + i / 16][cc][i % 16]; v = kq == o ? w : v; }
+    return v;
+  };
+  combine_and_store<CP, 16 * BPO>(val_of, row_of, col_ok, ncol, c, M, N, ksplit, partials, counters,
+                                  row_tile * col_tiles + col_tile, split, &s_last);
 }
 
 // ------------------------------------------------------------------ GPTQ, plain (unshuffled) weights + g_idx
@@ -960,42 +1234,85 @@ static int kmajor_gemm(void* c, const void* a, const uint32_t* qweight, const ui
     ap = a_perm;
   }
   float* partials = reinterpret_cast<float*>(ws + kCounterBytes);
-  // up to 128 rows: one row tile per workgroup, k split across its waves (every weight word is
-  // unpacked once); 129..256 rows: the LDS-tiled kernel, whose 8 waves share each A chunk
+  // Kernel choice, from measurements on the 13B / TP2 matrices (tools/quant_exp.hip):
+  //   * 128-row tile kernel: more than 128 rows, and 97..128 rows of wide matrices (it needs k in multiples of 256
+  //     and groups in multiples of 64);
+  //   * up to 128 rows otherwise: one row tile per workgroup, k split across its waves;
+  //   * 64-row tiled kernel: more than 128 rows of shapes the 128-row kernel does not take.
   int cp = 2, mt = M > 64 ? 4 : M > 32 ? 2 : 1;
   bool tiled = M > 128 && K % kChunkK == 0 && group_size % 16 == 0;
+  int waves = 8, chunk = kChunkK, tiled_mt = 2, force_ks = 0;
+  int t_variant = (K % 256 == 0 && group_size % 64 == 0 && (M > 128 || (M > 96 && N >= 12288))) ? 4 : 0;
 #ifdef SW_QUANT_EXPERIMENT                                     // tuning builds only: never in the shipped library
   if (const char* env = getenv("SW_QUANT_CP")) cp = atoi(env) == 4 ? 4 : 2;
   if (const char* env = getenv("SW_QUANT_MT")) mt = atoi(env);
   if (const char* env = getenv("SW_QUANT_TILED")) tiled = atoi(env) != 0 && K % kChunkK == 0;
+  if (const char* env = getenv("SW_QUANT_WAVES")) waves = atoi(env) == 4 ? 4 : 8;
+  if (const char* env = getenv("SW_QUANT_CHUNK")) chunk = atoi(env) == 128 ? 128 : 256;
+  if (const char* env = getenv("SW_QUANT_TMT")) tiled_mt = atoi(env);
+  if (const char* env = getenv("SW_QUANT_KSPLIT")) force_ks = atoi(env);
+  // 0: off; 2, 4: 128 rows x 8 waves with 2 / 4 k parts; 82, 84: 256 rows x 4 waves with 2 / 4 k parts
+  if (const char* env = getenv("SW_QUANT_T128")) t_variant = atoi(env);
 #endif
   if (mt == 3 || mt > 4) mt = 4;
-  // 128-row tiles would unpack a weight word once per four matrix instructions instead of two, but at two
-  // waves per SIMD (256 registers) their 128 accumulators plus the weight ring and the A staging spill
-  // (measured: 2-3x slower than the 64-row tiles, with 256-k and with 128-k chunks alike)
-  if (tiled && mt > 2) mt = 2;
-  const int chunk = kChunkK;
+  if (tiled) mt = tiled_mt;
+  if (t_variant != 0) {
+    const int t_rows = t_variant > 8 ? 256 : 128, t_kq = t_variant > 8 ? t_variant - 80 : t_variant;
+    const int t_cg = (t_variant > 8 ? 4 : 8) / t_kq;
+    SW_CHECK_ARG((t_kq == 2 || t_kq == 4) && K % (t_kq * 64) == 0 && group_size % 64 == 0,
+                 "gptq_gemm: no 128-row tile variant %d for K=%d, group size %d", t_variant, K, group_size);
+    const int rt = (M + t_rows - 1) / t_rows, ct = (N + 64 * t_cg - 1) / (64 * t_cg);
+    const int chunk_k = t_kq * 64;
+    int ks = pick_ksplit(ct * rt, K / chunk_k, 4, M, N, avail, 1, 256);
+    if (force_ks > 0 && force_ks <= K / chunk_k) ks = force_ks;
+#define SW_GPTQ_T128(MT_, KQ_, CG_, SPW_, NB_)                                                                 \
+  do {                                                                                                           \
+    auto kern = gptq_gemm_tile128_kernel<MT_, KQ_, CG_, SPW_, NB_>;                                              \
+    constexpr int lds_bytes = t128_lds<MT_, KQ_, SPW_, NB_>();                                                   \
+    SW_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                     lds_bytes));                                                                \
+    hipLaunchKernelGGL(kern, dim3((ct * rt * ks + 7) / 8 * 8), dim3(KQ_ * CG_ * 64), lds_bytes, st, out, ap,     \
+                       qweight, qzeros, sp, M, N, K, group_size, ks, ct, rt, zoff, partials, counters);          \
+  } while (0)
+    if (t_variant == 4) SW_GPTQ_T128(4, 4, 2, 4, 2);
+#ifdef SW_QUANT_EXPERIMENT
+    else if (t_variant == 2) SW_GPTQ_T128(4, 2, 4, 4, 3);
+    else if (t_variant == 82) SW_GPTQ_T128(8, 2, 2, 4, 2);
+#endif
+    else SW_CHECK_ARG(false, "gptq_gemm: no 128-row tile variant %d", t_variant);
+#undef SW_GPTQ_T128
+    SW_CHECK_LAUNCH();
+    return SW_OK;
+  }
   const int row_tiles = (M + 32 * mt - 1) / (32 * mt);
   if (tiled) {
-    const int tile_cols = 32 * cp * kGemmWaves;
+    const int tile_cols = 32 * cp * waves;
     const int col_tiles = (N + tile_cols - 1) / tile_cols;
-    const int ks = pick_ksplit(col_tiles * row_tiles, K / kChunkK, 2, M, N, avail, 1, 256);
+    int ks = pick_ksplit(col_tiles * row_tiles, K / chunk, 2, M, N, avail, 1, 256);
+    if (force_ks > 0 && force_ks <= K / chunk) ks = force_ks;
     const dim3 grid((col_tiles * row_tiles * ks + 7) / 8 * 8);
     const size_t lds = (size_t)2 * 32 * mt * (chunk * 2 + 16);
-#define SW_GPTQ_TILED(MT_, CP_)                                                                                 \
+#define SW_GPTQ_TILED(MT_, CP_, CHUNK_, WAVES_)                                                                 \
   do {                                                                                                          \
-    auto kern = gptq_gemm_tiled_kernel<MT_, CP_, (MT_ > 2 ? 128 : kChunkK)>;                                    \
+    auto kern = gptq_gemm_tiled_kernel<MT_, CP_, CHUNK_, WAVES_>;                                               \
     if (lds > 64 * 1024)                                                                                        \
       SW_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                     \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                  \
-    hipLaunchKernelGGL(kern, grid, dim3(kGemmWaves * 64), lds, st, out, ap, qweight, qzeros, sp, M, N, K,       \
+    hipLaunchKernelGGL(kern, grid, dim3(WAVES_ * 64), lds, st, out, ap, qweight, qzeros, sp, M, N, K,           \
                        group_size, ks, col_tiles, row_tiles, zoff, partials, counters);                         \
   } while (0)
-    if (mt == 1 && cp == 2) SW_GPTQ_TILED(1, 2);
-    else if (mt == 1) SW_GPTQ_TILED(1, 4);
-    else if (mt == 2 && cp == 2) SW_GPTQ_TILED(2, 2);
-    else if (mt == 2) SW_GPTQ_TILED(2, 4);
-    else SW_GPTQ_TILED(4, 2);
+    if (waves == 8) {
+      if (mt == 1) SW_GPTQ_TILED(1, 2, 256, 8);
+      else SW_GPTQ_TILED(2, 2, 256, 8);
+    } else {
+#ifdef SW_QUANT_EXPERIMENT
+      if (mt == 2 && chunk == 256) SW_GPTQ_TILED(2, 2, 256, 4);
+      else if (mt == 4 && chunk == 256) SW_GPTQ_TILED(4, 2, 256, 4);
+      else if (mt == 4) SW_GPTQ_TILED(4, 2, 128, 4);
+      else if (mt == 8) SW_GPTQ_TILED(8, 2, 128, 4);
+      else SW_CHECK_ARG(false, "no such tiled variant");
+#endif
+    }
 #undef SW_GPTQ_TILED
   } else {
     const int col_tiles = (N + 32 * cp - 1) / (32 * cp);
