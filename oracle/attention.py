@@ -71,9 +71,12 @@ def paged_attention(query: torch.Tensor, key_cache: torch.Tensor, value_cache: t
 
 def prefill_attention(query: torch.Tensor, key: torch.Tensor, value: torch.Tensor,
                       seq_lens: List[int], scale: float,
-                      alibi_slopes: Optional[torch.Tensor] = None) -> torch.Tensor:
+                      alibi_slopes: Optional[torch.Tensor] = None,
+                      sliding_window: Optional[int] = None) -> torch.Tensor:
     """Packed varlen causal attention: query [T, H, D], key/value [T, KVH, D],
-    tokens of sequence i occupy rows sum(seq_lens[:i]) ... ; returns [T, H, D]."""
+    tokens of sequence i occupy rows sum(seq_lens[:i]) ... ; returns [T, H, D].
+    With a sliding window a query sees the keys at distance 0 .. window - 1 behind it (the local
+    attention bias of backends/xformers.py:119-121)."""
     num_heads, kvh = query.shape[1], key.shape[1]
     g = num_heads // kvh
     dtype = query.dtype
@@ -88,6 +91,8 @@ def prefill_attention(query: torch.Tensor, key: torch.Tensor, value: torch.Tenso
             pos = torch.arange(n, dtype=torch.float32)
             w = w + alibi_slopes.float().view(-1, 1, 1) * (pos.view(1, 1, -1) - pos.view(1, -1, 1))
         mask = torch.triu(torch.ones(n, n, dtype=torch.bool), diagonal=1)
+        if sliding_window is not None:
+            mask |= torch.tril(torch.ones(n, n, dtype=torch.bool), diagonal=-sliding_window)
         w = w.masked_fill(mask, float("-inf"))
         p = torch.softmax(w, dim=-1).to(dtype).float()
         out[start:start + n] = torch.einsum("hqk,khd->qhd", p, v).to(dtype)

@@ -81,6 +81,26 @@ def test_padded_batch_layout_and_edge_lengths():
         assert torch.count_nonzero(out[s + n:s + max_len]) == 0
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("variant", ["plain", "alibi", "window"])
+def test_long_prompts_take_the_256_row_workgroups(dtype, variant):
+    """From 1536 tokens on a workgroup is 8 waves sharing each K / V stage: lengths around its 256-row and
+    64-key boundaries beside a short prompt in the same launch, with ALiBi and with a sliding window."""
+    torch.manual_seed(1)
+    h, kvh, d = 4, 2, 128
+    seq_lens = [1601, 37, 2048, 1537]
+    n = sum(seq_lens)
+    scale = float(d ** -0.5)
+    qkv = torch.empty(n, h + 2 * kvh, d, dtype=dtype).uniform_(-scale, scale)
+    q, k, v = qkv.split([h, kvh, kvh], dim=1)
+    alibi = torch.randn(h, dtype=torch.float) * 0.05 if variant == "alibi" else None
+    window = 700 if variant == "window" else None
+    ref = oattn.prefill_attention(q, k, v, seq_lens, scale, alibi, window)
+    qd, kd, vd = qkv.cuda().split([h, kvh, kvh], dim=1)
+    out = run(qd, kd, vd, seq_lens, scale, alibi.cuda() if alibi is not None else None, window=window)
+    torch.testing.assert_close(out.cpu().float(), ref.float(), atol=1e-3, rtol=1e-5)
+
+
 def test_float32_is_rejected():
     from splitwise_amd import _C
     q = torch.zeros(4, 2, 64, device="cuda")

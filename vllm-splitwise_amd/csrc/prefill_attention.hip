@@ -32,6 +32,7 @@
 //     fragments loaded straight from the paged cache layouts.
 #include "common.cuh"
 #include <float.h>
+#include <stdlib.h>
 #include <algorithm>
 #include <type_traits>
 
@@ -88,8 +89,8 @@ struct PfContext {
   int64_t k_block_stride, k_head_stride, v_block_stride, v_head_stride;   // elements
 };
 
-template <typename act_t, int HEAD, bool CTX>
-__global__ void __launch_bounds__(kPfWaves * 64, HEAD <= 128 ? 2 : 1)
+template <typename act_t, int HEAD, bool CTX, int WAVES>
+__global__ void __launch_bounds__(WAVES * 64, (HEAD <= 128 && WAVES == 4) ? 2 : 1)
 prefill_attention_kernel(uint16_t* __restrict__ out, const uint16_t* __restrict__ q,
                          const uint16_t* __restrict__ k, const uint16_t* __restrict__ v,
                          const int32_t* __restrict__ seq_starts, const int32_t* __restrict__ seq_lens,
@@ -111,7 +112,7 @@ prefill_attention_kernel(uint16_t* __restrict__ out, const uint16_t* __restrict_
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int KSTRIDE = pf_kstride(HEAD);
   constexpr int CHUNKS = kPfStage * CPR;             // 16-byte pieces of one stage of K (and of V)
-  constexpr int LOADS = (CHUNKS + kPfWaves * 64 - 1) / (kPfWaves * 64);
+  constexpr int LOADS = (CHUNKS + WAVES * 64 - 1) / (WAVES * 64);
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -122,7 +123,7 @@ prefill_attention_kernel(uint16_t* __restrict__ out, const uint16_t* __restrict_
   const int head = blockIdx.y;
   const int seq_len = seq_lens[seq];
   // heavy (late) query tiles first: they have the longest key loops under the causal mask
-  const int q_base = (gridDim.x - 1 - blockIdx.x) * kPfWaves * kPfRows;
+  const int q_base = (gridDim.x - 1 - blockIdx.x) * WAVES * kPfRows;
   if (q_base >= seq_len) return;                     // workgroup-uniform
   const int q0 = q_base + wave * kPfRows;
   const bool active = q0 < seq_len;                  // wave-uniform; idle waves still load tiles and meet barriers
@@ -145,7 +146,7 @@ prefill_attention_kernel(uint16_t* __restrict__ out, const uint16_t* __restrict_
 
   // zero the V images once: pad columns HEAD..DP-1 must read as 0 (never written again)
   if constexpr (DP != HEAD) {
-    for (int i = tid; i < kPfBufs * kPfStage * VSTRIDE / 16; i += kPfWaves * 64)
+    for (int i = tid; i < kPfBufs * kPfStage * VSTRIDE / 16; i += WAVES * 64)
       reinterpret_cast<uint4*>(v_img)[i] = make_uint4(0, 0, 0, 0);
     __syncthreads();
   }
@@ -303,7 +304,7 @@ prefill_attention_kernel(uint16_t* __restrict__ out, const uint16_t* __restrict_
   const int k_end = min(q0 + kPfRows, seq_len);      // this wave's keys: < k_end
   int k_begin = 0;
   if (sliding_window > 0) k_begin = max(0, (q0 - sliding_window + 1) / kPfKeys * kPfKeys);
-  const int wg_end = min(q_base + kPfWaves * kPfRows, seq_len);
+  const int wg_end = min(q_base + WAVES * kPfRows, seq_len);
   int wg_begin = 0;
   if (sliding_window > 0) wg_begin = max(0, (q_base - sliding_window + 1) / kPfStage * kPfStage);
 
@@ -323,7 +324,7 @@ prefill_attention_kernel(uint16_t* __restrict__ out, const uint16_t* __restrict_
   uint32_t koff[LOADS], voff[LOADS];
 #pragma unroll
   for (int it = 0; it < LOADS; ++it) {
-    const int c = it * kPfWaves * 64 + tid;
+    const int c = it * WAVES * 64 + tid;
     const int key = c / CPR, ch = c - key * CPR;
     koff[it] = (uint32_t)(key * k_stride + ch * 8) * 2u;
     voff[it] = (uint32_t)(key * v_stride + ch * 8) * 2u;
@@ -334,7 +335,7 @@ prefill_attention_kernel(uint16_t* __restrict__ out, const uint16_t* __restrict_
     const uint32_t k_stage = (uint32_t)t0 * (uint32_t)k_stride * 2u, v_stage = (uint32_t)t0 * (uint32_t)v_stride * 2u;
     static_for<LOADS>([&](auto IT) {
       constexpr int it = decltype(IT)::value;
-      if (CHUNKS % (kPfWaves * 64) == 0 || it * kPfWaves * 64 + tid < CHUNKS) {
+      if (CHUNKS % (WAVES * 64) == 0 || it * WAVES * 64 + tid < CHUNKS) {
         kreg[it] = __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, (int)(koff[it] + k_stage), 0, 0);
         vreg[it] = __builtin_amdgcn_raw_buffer_load_b128(v_rsrc, (int)(voff[it] + v_stage), 0, 0);
       }
@@ -343,8 +344,8 @@ prefill_attention_kernel(uint16_t* __restrict__ out, const uint16_t* __restrict_
   auto commit = [&](int buf) {
     static_for<LOADS>([&](auto IT) {
       constexpr int it = decltype(IT)::value;
-      const int c = it * kPfWaves * 64 + tid;
-      if (CHUNKS % (kPfWaves * 64) == 0 || c < CHUNKS) {
+      const int c = it * WAVES * 64 + tid;
+      if (CHUNKS % (WAVES * 64) == 0 || c < CHUNKS) {
         const int key = c / CPR, ch = c - key * CPR;
         *reinterpret_cast<u32x4*>(k_img + (buf * kPfStage + key) * KSTRIDE + ch * 16) = kreg[it];
         *reinterpret_cast<u32x4*>(v_img + (buf * kPfStage + key) * VSTRIDE + ch * 16) = vreg[it];
@@ -479,25 +480,49 @@ prefill_attention_kernel(uint16_t* __restrict__ out, const uint16_t* __restrict_
   }
 }
 
-template <typename act_t, int HEAD, bool CTX>
-int launch_prefill(void* out, const void* q, const void* k, const void* v, const int32_t* seq_starts,
-                   const int32_t* seq_lens, int num_seqs, int max_seq_len, int num_heads, int num_kv_heads,
-                   float scale, const float* alibi, int64_t q_stride, int64_t k_stride, int64_t v_stride,
-                   int64_t out_stride, int sliding_window, const PfContext& cx, hipStream_t stream) {
-  const int rows_per_wg = kPfWaves * kPfRows;
+template <typename act_t, int HEAD, bool CTX, int WAVES>
+int launch_prefill_w(void* out, const void* q, const void* k, const void* v, const int32_t* seq_starts,
+                     const int32_t* seq_lens, int num_seqs, int max_seq_len, int num_heads, int num_kv_heads,
+                     float scale, const float* alibi, int64_t q_stride, int64_t k_stride, int64_t v_stride,
+                     int64_t out_stride, int sliding_window, const PfContext& cx, hipStream_t stream) {
+  const int rows_per_wg = WAVES * kPfRows;
   dim3 grid((max_seq_len + rows_per_wg - 1) / rows_per_wg, num_heads, num_seqs);
   const size_t smem = (size_t)pf_lds_bytes(HEAD);
-  auto kern = prefill_attention_kernel<act_t, HEAD, CTX>;
+  auto kern = prefill_attention_kernel<act_t, HEAD, CTX, WAVES>;
 
   if (smem > 64 * 1024)
     SW_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)smem));
-  kern<<<grid, kPfWaves * 64, smem, stream>>>(
+  kern<<<grid, WAVES * 64, smem, stream>>>(
       static_cast<uint16_t*>(out), static_cast<const uint16_t*>(q), static_cast<const uint16_t*>(k),
       static_cast<const uint16_t*>(v), seq_starts, seq_lens, num_heads, num_kv_heads, scale, alibi, q_stride,
       k_stride, v_stride, out_stride, sliding_window, cx);
   SW_CHECK_LAUNCH();
   return SW_OK;
+}
+
+// 4 waves (128 query rows) per workgroup, two workgroups per CU; from kPfWideFrom tokens on, without a cached
+// context, 8 waves (256 query rows) share every K / V stage: half the staging traffic per score
+constexpr int kPfWideFrom = 1536;
+
+template <typename act_t, int HEAD, bool CTX>
+int launch_prefill(void* out, const void* q, const void* k, const void* v, const int32_t* seq_starts,
+                   const int32_t* seq_lens, int num_seqs, int max_seq_len, int num_heads, int num_kv_heads,
+                   float scale, const float* alibi, int64_t q_stride, int64_t k_stride, int64_t v_stride,
+                   int64_t out_stride, int sliding_window, const PfContext& cx, hipStream_t stream) {
+  int wide = !CTX && HEAD <= 128 && max_seq_len >= kPfWideFrom;
+#ifdef SW_PREFILL_EXPERIMENT
+  if (const char* env = getenv("SW_PREFILL_WIDE")) wide = !CTX && HEAD <= 128 && atoi(env) != 0;
+#endif
+  if constexpr (!CTX && HEAD <= 128) {
+    if (wide)
+      return launch_prefill_w<act_t, HEAD, CTX, 8>(out, q, k, v, seq_starts, seq_lens, num_seqs, max_seq_len, num_heads,
+                                                   num_kv_heads, scale, alibi, q_stride, k_stride, v_stride, out_stride,
+                                                   sliding_window, cx, stream);
+  }
+  return launch_prefill_w<act_t, HEAD, CTX, kPfWaves>(out, q, k, v, seq_starts, seq_lens, num_seqs, max_seq_len,
+                                                      num_heads, num_kv_heads, scale, alibi, q_stride, k_stride,
+                                                      v_stride, out_stride, sliding_window, cx, stream);
 }
 
 int prefill_entry(void* out, const void* query, const void* key, const void* value, const int32_t* seq_starts,
