@@ -60,6 +60,8 @@ int main(int argc, char** argv) {
       {"t128 kq4 ks1", "8", "2", "256", "1", "4"},
       {"t256 kq2 auto", "8", "2", "256", nullptr, "82"},
       {"t256 kq2 ks1", "8", "2", "256", "1", "82"},
+      {"t256 kq4cg1 ks1", "8", "2", "256", "1", "84"},
+      {"t256 kq4cg1 ks2", "8", "2", "256", "2", "84"},
       {"t256 kq2 ks2", "8", "2", "256", "2", "82"},
       {"t256 kq2 ks3", "8", "2", "256", "3", "82"},
       {"t256 kq2 ks4", "8", "2", "256", "4", "82"},

@@ -649,6 +649,12 @@ gptq_gemm_tile128_kernel(uint16_t* __restrict__ c, const uint16_t* __restrict__ 
     // Three buffers: the pieces of chunk + 2 are requested while those of chunk + 1, requested a chunk ago, go into
     // buf_next (nobody reads it any more after this barrier).  Two buffers: a thread holds one half of a chunk at a
     // time, so a half is written half a chunk after it was requested.
+    if constexpr (MT > 4) {                              // 256 accumulator registers: keep them in the AGPR half
+#pragma unroll
+      for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int cc = 0; cc < CP; ++cc) asm volatile("" : "+a"(acc[t][cc]));
+    }
     if constexpr (NBUF == 2) a_commit(H1{}, buf_cur * ABUF);
     __syncthreads();
     if constexpr (NBUF == 3) a_commit(H0{}, buf_next * ABUF);
@@ -1267,7 +1273,7 @@ static int kmajor_gemm(void* c, const void* a, const uint32_t* qweight, const ui
     SW_CHECK_ARG((t_kq == 2 || t_kq == 4) && K % (t_kq * 64) == 0 && group_size % 64 == 0,
                  "gptq_gemm: no 128-row tile variant %d for K=%d, group size %d", t_variant, K, group_size);
     const int rt = (M + t_rows - 1) / t_rows, ct = (N + 64 * t_cg - 1) / (64 * t_cg);
-    const int chunk_k = t_kq * 64;
+    const int chunk_k = t_variant == 84 ? 128 : t_kq * 64;
     int ks = pick_ksplit(ct * rt, K / chunk_k, 4, M, N, avail, 1, 256);
     if (force_ks > 0 && force_ks <= K / chunk_k) ks = force_ks;
 #define SW_GPTQ_T128(MT_, KQ_, CG_, SPW_, NB_)                                                                 \
@@ -1283,6 +1289,7 @@ static int kmajor_gemm(void* c, const void* a, const uint32_t* qweight, const ui
 #ifdef SW_QUANT_EXPERIMENT
     else if (t_variant == 2) SW_GPTQ_T128(4, 2, 4, 4, 3);
     else if (t_variant == 82) SW_GPTQ_T128(8, 2, 2, 4, 2);
+    else if (t_variant == 84) SW_GPTQ_T128(8, 4, 1, 2, 2);
 #endif
     else SW_CHECK_ARG(false, "gptq_gemm: no 128-row tile variant %d", t_variant);
 #undef SW_GPTQ_T128
