@@ -568,6 +568,7 @@ gptq_gemm_tile128_kernel(uint16_t* __restrict__ c, const uint16_t* __restrict__ 
   constexpr int PPT = BM * SEGS / NT;                 // pieces per thread and chunk
   constexpr int PH = PPT / 2;                         // moved in two halves, at the top and in the middle of a chunk
   static_assert(PPT % 2 == 0 && BPO >= 1, "tile shape");
+  static_assert(KQ * CG * 32 * 64 * 4 <= NBUF * ABUF, "the A buffers must hold one 32-register block per wave at the end");
   extern __shared__ __attribute__((aligned(16))) char a_lds[];
   __shared__ int s_last;
   const int tid = threadIdx.x;
