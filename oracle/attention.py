@@ -102,13 +102,16 @@ def prefill_attention(query: torch.Tensor, key: torch.Tensor, value: torch.Tenso
 
 def context_attention(query: torch.Tensor, key: torch.Tensor, value: torch.Tensor, key_cache: torch.Tensor,
                       value_cache: torch.Tensor, block_tables: torch.Tensor, new_lens: List[int],
-                      ctx_lens: List[int], alibi_slopes: Optional[torch.Tensor] = None) -> torch.Tensor:
+                      ctx_lens: List[int], alibi_slopes: Optional[torch.Tensor] = None,
+                      sliding_window: Optional[int] = None) -> torch.Tensor:
     """Prompt attention over a cached prefix: what ``context_attention_fwd`` computes
     (vllm/model_executor/layers/attention/ops/prefix_prefill.py:10-745) and what its test compares
     with (tests/kernels/test_prefix_prefill.py:126-176: causal "from bottom right" attention of the
     new tokens over context + new tokens, scale D^-1/2).  query [T, H, D] and key/value [T, KVH, D]
     hold the NEW tokens of all sequences back to back; the context lives in the paged caches.
-    ALiBi bias = slope * (key position - query position), as in _fwd_kernel_alibi (:433-618)."""
+    ALiBi bias = slope * (key position - query position), as in _fwd_kernel_alibi (:433-618).
+    A sliding window (not in the reference's prefix kernel; the same rule as in prefill_attention) lets a
+    query see the keys at distance 0 .. window - 1 behind it, cached or new."""
     num_heads, kvh, head = query.shape[1], key.shape[1], query.shape[2]
     g = num_heads // kvh
     dtype = query.dtype
@@ -126,7 +129,10 @@ def context_attention(query: torch.Tensor, key: torch.Tensor, value: torch.Tenso
         kpos = torch.arange(ctx + n, dtype=torch.float32)
         if alibi_slopes is not None:
             w = w + alibi_slopes.float().view(-1, 1, 1) * (kpos.view(1, 1, -1) - qpos.view(1, -1, 1))
-        w = w.masked_fill((kpos.view(1, -1) > qpos.view(-1, 1)).unsqueeze(0), float("-inf"))
+        mask = kpos.view(1, -1) > qpos.view(-1, 1)
+        if sliding_window is not None:
+            mask = mask | (qpos.view(-1, 1) - kpos.view(1, -1) >= sliding_window)
+        w = w.masked_fill(mask.unsqueeze(0), float("-inf"))
         p = torch.softmax(w, dim=-1).to(dtype).float()
         out[start:start + n] = torch.einsum("hqk,khd->qhd", p, v).to(dtype)
         start += n

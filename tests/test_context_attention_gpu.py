@@ -71,6 +71,37 @@ def test_contexted_kv_attention(num_heads, num_queries_per_kv, head_size, dtype)
     torch.testing.assert_close(out.float(), ref.float(), atol=1e-6, rtol=1e-2)
 
 
+@pytest.mark.parametrize("head_size,block_size", [(80, 16), (112, 32), (128, 4), (64, 8), (256, 16)])
+def test_both_context_paths(head_size, block_size):
+    """The cached context goes through LDS, shared by the workgroup, when a block holds 8 consecutive keys of a
+    head element and the head size is a multiple of 32; other shapes read it straight from the cache, wave by
+    wave.  Both against the oracle, on caches whose unwritten slots hold NaN."""
+    dtype = torch.bfloat16
+    new_lens = [70, 1, 129, 40]
+    ctx_lens = [130, 77, 0, 513]
+    s = head_size ** -0.5
+    q, k, v, kc, vc, table = _case(8, 4, head_size, dtype, block_size, new_lens, ctx_lens, scale_inputs=s, seed=7)
+    out = _run(q, k, v, kc, vc, table, new_lens, ctx_lens)
+    ref = oattn.context_attention(q, k, v, kc, vc, table, new_lens, ctx_lens)
+    assert not torch.isnan(out.float()).any()
+    torch.testing.assert_close(out.float(), ref.float(), atol=1e-3, rtol=1e-2)
+
+
+@pytest.mark.parametrize("block_size", [4, 16])
+def test_sliding_window_over_the_cached_context(block_size):
+    """Windows that end inside the context, inside the new tokens, and beyond everything."""
+    dtype, head = torch.float16, 128
+    new_lens = [100, 33, 260]
+    ctx_lens = [300, 64, 200]
+    s = head ** -0.5
+    q, k, v, kc, vc, table = _case(4, 2, head, dtype, block_size, new_lens, ctx_lens, scale_inputs=s, seed=9)
+    for window in (50, 150, 1000):
+        out = _run(q, k, v, kc, vc, table, new_lens, ctx_lens, window=window)
+        ref = oattn.context_attention(q, k, v, kc, vc, table, new_lens, ctx_lens, None, window)
+        assert not torch.isnan(out.float()).any()
+        torch.testing.assert_close(out.float(), ref.float(), atol=1e-3, rtol=1e-3)
+
+
 @pytest.mark.parametrize("block_size", [16, 32])
 @pytest.mark.parametrize("use_alibi", [False, True])
 def test_edge_lengths_alibi_and_unit_scale(block_size, use_alibi):

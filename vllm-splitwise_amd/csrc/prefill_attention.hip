@@ -221,8 +221,137 @@ prefill_attention_kernel(uint16_t* __restrict__ out, const uint16_t* __restrict_
   };
   using One = std::integral_constant<int, 1>;
 
-  if (CTX && active) {
-    // ---- phase 1: the cached context.  Both operands come straight from the cache layouts: 8
+  using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
+  // The shared form of phase 1 needs 8 consecutive keys of a head element in one block and no pad rows in O^T
+  const bool ctx_shared = CTX && DP == HEAD && cx.block_size % 8 == 0;
+  if (CTX && ctx_shared) {
+    // ---- phase 1, shared: the cached context goes through LDS in stages of kPfStage keys, like the new tokens in
+    // phase 2, so the workgroup's waves read every cached key and value once between them instead of once each.
+    // K pieces (16 bytes = 8 head elements of a key) land in the row-major K image of phase 2.  The value cache is
+    // already V^T ([head element][key]), which is what the P.V product wants as its A operand: its 16-byte pieces
+    // (8 keys of a head element) build a [head element][key] image in the V buffers, read back with plain 8-byte
+    // reads -- no transposing read here.
+    constexpr int VTS = kPfStage * 2 + 8;              // bytes per V^T row: 32 rows on distinct bank pairs
+    static_assert(HEAD * VTS <= kPfStage * VSTRIDE, "the V^T image must fit a V buffer");
+    const int ctx = cx.ctx_lens[seq];
+    const int32_t* table = cx.block_tables + (int64_t)seq * cx.max_blocks;
+    const int bs = cx.block_size;
+    const int q_abs = ctx + q_idx;
+    int c0 = 0;
+    if (sliding_window > 0) c0 = max(0, (ctx + q_base - sliding_window + 1) / kPfStage * kPfStage);
+    const int cstages = ctx > c0 ? (ctx - c0 + kPfStage - 1) / kPfStage : 0;       // workgroup-uniform
+    u32x4 ckreg[LOADS], cvreg[LOADS];
+    auto cfetch = [&](int k0) {
+      static_for<LOADS>([&](auto IT) {
+        constexpr int it = decltype(IT)::value;
+        const int c = it * WAVES * 64 + tid;
+        if (CHUNKS % (WAVES * 64) == 0 || c < CHUNKS) {
+          const int kk = min(k0 + c / CPR, ctx - 1), ch = c % CPR;       // keys past the context: any valid address
+          const uint16_t* kp = cx.k_cache + (int64_t)table[kk / bs] * cx.k_block_stride +
+                               (int64_t)kv_head * cx.k_head_stride + (int64_t)ch * bs * 8 + (kk % bs) * 8;
+          ckreg[it] = *reinterpret_cast<const u32x4*>(kp);
+          const int d = c / (kPfStage / 8), key0 = k0 + 8 * (c % (kPfStage / 8));
+          const int kc = min(key0, ctx - 1) & ~7;
+          const uint16_t* vp = cx.v_cache + (int64_t)table[kc / bs] * cx.v_block_stride +
+                               (int64_t)kv_head * cx.v_head_stride + (int64_t)d * bs + (kc % bs);
+          u32x4 w = *reinterpret_cast<const u32x4*>(vp);
+          const int valid = ctx - key0;                                  // never-written slots may hold NaN patterns
+          if (valid < 8) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              if (2 * i + 0 >= valid) w[i] &= 0xffff0000u;
+              if (2 * i + 1 >= valid) w[i] &= 0x0000ffffu;
+            }
+          }
+          cvreg[it] = w;
+        }
+      });
+    };
+    auto ccommit = [&](int buf) {
+      static_for<LOADS>([&](auto IT) {
+        constexpr int it = decltype(IT)::value;
+        const int c = it * WAVES * 64 + tid;
+        if (CHUNKS % (WAVES * 64) == 0 || c < CHUNKS) {
+          const int key = c / CPR, ch = c - key * CPR;
+          *reinterpret_cast<u32x4*>(k_img + (buf * kPfStage + key) * KSTRIDE + ch * 16) = ckreg[it];
+          const int d = c / (kPfStage / 8), g8 = c % (kPfStage / 8);
+          *reinterpret_cast<u32x4*>(v_img + buf * kPfStage * VSTRIDE + d * VTS + g8 * 16) = cvreg[it];
+        }
+      });
+    };
+    if (cstages > 0) {
+      cfetch(c0);
+      ccommit(0);
+      if (cstages > 1) cfetch(c0 + kPfStage);
+      __syncthreads();
+    }
+    int cbuf = 0;
+    for (int t = 0; t < cstages; ++t) {                  // every wave meets every barrier
+      const int k0 = c0 + t * kPfStage;
+      if (t + 1 < cstages) ccommit(cbuf ^ 1);
+      if (t + 2 < cstages) cfetch(k0 + 2 * kPfStage);
+      // (wave-uniform) this wave's window may begin after the stage
+      const bool wanted = active && (sliding_window <= 0 || k0 + kPfStage > ctx + q0 - sliding_window + 1);
+      if (wanted) {
+        const char* kb = k_img + cbuf * kPfStage * KSTRIDE + col * KSTRIDE + half * 16;
+        const char* vt = v_img + cbuf * kPfStage * VSTRIDE + col * VTS + 8 * half;
+        f32x16 sv[NT];
+#pragma unroll
+        for (int u = 0; u < NT; ++u) {
+          f32x16 acc;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+          for (int h0 = 0; h0 < KS; h0 += 4) {
+            frag kf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              if (h0 + i < KS) kf[i] = *reinterpret_cast<const frag*>(kb + u * kPfKeys * KSTRIDE + 32 * (h0 + i));
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              if (h0 + i < KS) acc = M::run(kf[i], qf[h0 + i], acc);
+          }
+          sv[u] = acc;
+        }
+#pragma unroll
+        for (int u = 0; u < NT; ++u) {
+          const int kt = k0 + u * kPfKeys;
+          if (kt + kPfKeys <= ctx && slope == 0.f && sliding_window <= 0) {      // wave-uniform: nothing to mask
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sv[u][r] *= scale2;
+          } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int key = kt + (r & 3) + 8 * (r >> 2) + 4 * half;
+              float x = sv[u][r] * scale2;
+              if (slope != 0.f) x += slope2 * (float)(key - q_abs);
+              bool ok = key < ctx;
+              if (sliding_window > 0) ok = ok && (q_abs - key < sliding_window);
+              sv[u][r] = ok ? x : -INFINITY;
+            }
+          }
+        }
+        frag pt[2 * NT];
+        softmax_step(std::integral_constant<int, NT>{}, sv, pt);
+        // O^T += V^T . P^T; A operand element j <-> key 16*st + 8*(j>>2) + 4*half + (j&3) of the tile
+#pragma unroll
+        for (int u = 0; u < NT; ++u)
+#pragma unroll
+          for (int st = 0; st < 2; ++st)
+#pragma unroll
+            for (int b = 0; b < DB; ++b) {
+              const char* base = vt + b * 32 * VTS + (32 * u + 16 * st) * 2;
+              union { uint2 p[2]; frag f; } vf;
+              vf.p[0] = *reinterpret_cast<const uint2*>(base);
+              vf.p[1] = *reinterpret_cast<const uint2*>(base + 16);
+              o[b] = M::run(vf.f, pt[2 * u + st], o[b]);
+            }
+      }
+      __syncthreads();
+      cbuf ^= 1;
+    }
+  } else if (CTX && active) {
+    // ---- phase 1, direct (odd block sizes and head sizes): the cached context.  Both operands come straight from the cache layouts: 8
     // contiguous head elements of a key are one 16-byte group of the key cache, and 4 contiguous
     // keys of one head element are 8 bytes of the value cache (= a piece of V^T).
     const int ctx = cx.ctx_lens[seq];
@@ -308,7 +437,6 @@ prefill_attention_kernel(uint16_t* __restrict__ out, const uint16_t* __restrict_
   int wg_begin = 0;
   if (sliding_window > 0) wg_begin = max(0, (q_base - sliding_window + 1) / kPfStage * kPfStage);
 
-  using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
   // (native vectors: arrays of HIP's uint4 struct, assigned under a condition, are kept in scratch
   //  memory by the compiler)
   u32x4 kreg[LOADS], vreg[LOADS];
