@@ -69,6 +69,9 @@ int main(int argc, char** argv) {
       {"t128 kq4 ks3", "8", "2", "256", "3", "4"},
       {"t128 kq4 ks4", "8", "2", "256", "4", "4"},
       {"w8 mt2 ks1", "8", "2", "256", "1"},
+      {"shipped path ks2", "8", "2", "256", "2"},
+      {"shipped path ks3", "8", "2", "256", "3"},
+      {"shipped path ks4", "8", "2", "256", "4"},
   };
   std::vector<uint16_t> ref((size_t)M * N), got((size_t)M * N);
   const char* only = argc > 4 ? argv[4] : nullptr;
