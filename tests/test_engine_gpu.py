@@ -63,6 +63,25 @@ def test_greedy_generation_matches_cpu_model(model, enforce_eager):
     torch.cuda.empty_cache()
 
 
+def test_opt_125m_geometry_greedy_generation_matches_cpu_model():
+    """The reference's own CPU-runnable case (examples/offline_inference.py: OPT-125m, greedy): the full geometry --
+    12 layers, 768 hidden, 12 heads of 64, vocabulary 50272, learned positions -- with random weights, eager and
+    with captured decode graphs, against the CPU model."""
+    from splitwise_amd import LLM, SamplingParams
+    random.seed(3)
+    for eager in (True, False):
+        llm = LLM("opt-125m", enforce_eager=eager, num_gpu_blocks_override=128, max_num_seqs=4, max_model_len=256,
+                  swap_space=0.01)
+        vocab = llm.llm_engine.model_config.get_vocab_size()
+        assert vocab == 50272
+        prompts = [[random.randrange(vocab) for _ in range(n)] for n in (6, 40, 17, 1)]
+        outs = llm.generate(prompt_token_ids=prompts, sampling_params=SamplingParams(temperature=0.0, max_tokens=8))
+        assert all(len(o.outputs[0].token_ids) == 8 for o in outs)
+        _check_greedy(llm, prompts, outs, tol=3e-2)
+        del llm
+        torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("sep,pipeline", [(False, False), (False, True), (True, False)])
 def test_prefix_caching_reuses_blocks_and_generates_like_the_cpu_model(sep, pipeline, monkeypatch):
     """enable_prefix_caching: prompts that start with the same tokens share KV blocks; once those are computed a
