@@ -107,11 +107,6 @@ __device__ __forceinline__ DequantRegs dequant_regs() {
   return k;
 }
 __device__ __forceinline__ f16x8 gptq_dequant8(uint32_t w, const GptqCol& col, const DequantRegs& k) {
-#ifdef SW_QUANT_NODEQ                                          // timing probe: no unpacking arithmetic
-  union { uint32_t u[4]; f16x8 f; } q;
-  q.u[0] = w; q.u[1] = w ^ k.lo; q.u[2] = w; q.u[3] = w ^ k.hi;
-  return q.f;
-#endif
   const h2 y16 = splat((_Float16)0.0625f);
   const h2 q0 = as_h2((w & k.lo) | k.magic);
   const h2 q1 = as_h2((w & k.hi) | k.magic);
