@@ -103,6 +103,23 @@ def test_gptq_gemm_shuffled(m, k, n, group):
     _close(got, quant.gptq_gemm(a, w, qzeros, scales, None, True))
 
 
+def test_gptq_gemm_tile_kernel_on_seeded_random_shapes():
+    """Shapes drawn at random inside the 128-row tile kernel's domain (rows 129..256, k in multiples of 256,
+    columns in multiples of 8, groups of 64 / 128 / 256 / all of k), against the CPU restatement."""
+    from splitwise_amd import _C
+    rng = np.random.default_rng(2024)
+    for case in range(10):
+        m = int(rng.integers(129, 257))
+        k = 256 * int(rng.integers(1, 9))
+        n = 8 * int(rng.integers(1, 200))
+        group = int(rng.choice([g for g in (64, 128, 256, k) if k % g == 0]))
+        qweight, qzeros, scales, _ = _gptq_case(k, n, group, 1000 + case)
+        a = rng.standard_normal((m, k)).astype(np.float16)
+        w = quant.gptq_shuffle(qweight)
+        got = _C.ops.gptq_gemm(_dev(a), _dev(w), _dev(qzeros), _dev(scales), torch.empty((1, 1), device="meta"), True, 4)
+        _close(got, quant.gptq_gemm(a, w, qzeros, scales, None, True))
+
+
 @pytest.mark.parametrize("m,k,n,group", [(1, 512, 256, 128), (9, 1024, 520, 64), (48, 512, 128, 32), (70, 512, 136, 128),
                                          (140, 512, 264, 128)])
 def test_gptq_gemm_act_order(m, k, n, group):
