@@ -271,7 +271,7 @@ __device__ __forceinline__ void combine_and_store(ValOf val_of, RowOf row_of, bo
   }
   if (!last) return;
   // the final sum, RB rows at a time (all of a thread's loads of one split and block are issued before the first is used)
-  constexpr int RB = ROWS > 32 ? 16 : ROWS;
+  constexpr int RB = ROWS > 16 ? 16 : ROWS;              // three RB x CP register sets are live at once
   static_assert(ROWS % RB == 0, "row blocks must tile the thread's rows");
 #pragma unroll
   for (int b0 = 0; b0 < ROWS; b0 += RB) {
@@ -281,8 +281,17 @@ __device__ __forceinline__ void combine_and_store(ValOf val_of, RowOf row_of, bo
 #pragma unroll
       for (int cc = 0; cc < CP; ++cc) v[i][cc] = ksplit > 1 ? 0.f : val_of(b0 + i, cc);
     if (ksplit > 1) {
-      for (int z = 0; z < ksplit; ++z) {                  // fixed order: reproducible
-        float p[RB][CP];
+      // The splits are added in the fixed order 0, 1, ... whoever arrived last (reproducible); this workgroup's own
+      // partial comes from its registers, not from memory, and the loads of split z+1 are in flight while split z
+      // is added.
+      auto take = [&](int z, float (&p)[RB][CP]) {
+        if (z == split) {                                 // workgroup-uniform
+#pragma unroll
+          for (int i = 0; i < RB; ++i)
+#pragma unroll
+            for (int cc = 0; cc < CP; ++cc) p[i][cc] = val_of(b0 + i, cc);
+          return;
+        }
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
           const int m = row_of(b0 + i);
@@ -297,10 +306,20 @@ __device__ __forceinline__ void combine_and_store(ValOf val_of, RowOf row_of, bo
             p[i][0] = __uint_as_float(q.x); p[i][1] = __uint_as_float(q.y);
           }
         }
+      };
+      auto add = [&](const float (&p)[RB][CP]) {
 #pragma unroll
         for (int i = 0; i < RB; ++i)
 #pragma unroll
           for (int cc = 0; cc < CP; ++cc) v[i][cc] += p[i][cc];
+      };
+      float pa[RB][CP], pb[RB][CP];
+      take(0, pa);
+      for (int z = 0; z < ksplit; z += 2) {
+        if (z + 1 < ksplit) take(z + 1, pb);
+        add(pa);
+        if (z + 2 < ksplit) take(z + 2, pa);
+        if (z + 1 < ksplit) add(pb);
       }
     }
 #pragma unroll
@@ -1242,14 +1261,14 @@ static int kmajor_gemm(void* c, const void* a, const uint32_t* qweight, const ui
   }
   float* partials = reinterpret_cast<float*>(ws + kCounterBytes);
   // Kernel choice, from measurements on the 13B / TP2 matrices (tools/quant_exp.hip):
-  //   * 128-row tile kernel: more than 128 rows, and 97..128 rows of wide matrices (it needs k in multiples of 256
-  //     and groups in multiples of 64);
+  //   * 128-row tile kernel: more than 128 rows, and 97..128 rows of matrices with 7680 columns or more (it needs
+  //     k in multiples of 256 and groups in multiples of 64);
   //   * up to 128 rows otherwise: one row tile per workgroup, k split across its waves;
   //   * 64-row tiled kernel: more than 128 rows of shapes the 128-row kernel does not take.
   int cp = 2, mt = M > 64 ? 4 : M > 32 ? 2 : 1;
   bool tiled = M > 128 && K % kChunkK == 0 && group_size % 16 == 0;
   int waves = 8, chunk = kChunkK, tiled_mt = 2, force_ks = 0;
-  int t_variant = (K % 256 == 0 && group_size % 64 == 0 && (M > 128 || (M > 96 && N >= 12288))) ? 4 : 0;
+  int t_variant = (K % 256 == 0 && group_size % 64 == 0 && (M > 128 || (M > 96 && N >= 7680))) ? 4 : 0;
 #ifdef SW_QUANT_EXPERIMENT                                     // tuning builds only: never in the shipped library
   if (const char* env = getenv("SW_QUANT_CP")) cp = atoi(env) == 4 ? 4 : 2;
   if (const char* env = getenv("SW_QUANT_MT")) mt = atoi(env);
