@@ -84,10 +84,11 @@ def test_padded_batch_layout_and_edge_lengths():
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("variant", ["plain", "alibi", "window"])
 def test_long_prompts_take_the_256_row_workgroups(dtype, variant):
-    """From 1536 tokens on a workgroup is 8 waves sharing each K / V stage: lengths around its 256-row and
-    64-key boundaries beside a short prompt in the same launch, with ALiBi and with a sliding window."""
+    """Launches with a prompt of 2048 tokens or more and at least 384 tiles of 256 query rows run workgroups of
+    8 waves sharing each K / V stage (here 8 tiles x 12 heads x 4 prompts): lengths around the 256-row and 64-key
+    boundaries beside a short prompt in the same launch, with ALiBi and with a sliding window."""
     torch.manual_seed(1)
-    h, kvh, d = 4, 2, 128
+    h, kvh, d = 12, 4, 128
     seq_lens = [1601, 37, 2048, 1537]
     n = sum(seq_lens)
     scale = float(d ** -0.5)

@@ -73,6 +73,7 @@ __host__ __device__ constexpr int pf_vstride(int head) {          // bytes per V
 __host__ __device__ constexpr int pf_kstride(int head) {          // bytes per K row in LDS: 16 rows on 64 distinct banks
   return head * 2 + 16;
 }
+constexpr int kQkAhead = 4;                          // K fragments requested ahead of the product that uses them
 constexpr int kPfBufs = 2;                           // LDS stages: one in use, one landing
 __host__ __device__ constexpr int pf_lds_bytes(int head) {        // kPfBufs stages of a K and a V image
   return kPfBufs * pf_tiles(head) * kPfKeys * (pf_kstride(head) + pf_vstride(head));
@@ -96,7 +97,8 @@ prefill_attention_kernel(uint16_t* __restrict__ out, const uint16_t* __restrict_
                          const int32_t* __restrict__ seq_starts, const int32_t* __restrict__ seq_lens,
                          int num_heads, int num_kv_heads, float scale,
                          const float* __restrict__ alibi_slopes, int64_t q_stride, int64_t k_stride,
-                         int64_t v_stride, int64_t out_stride, int sliding_window, PfContext cx) {
+                         int64_t v_stride, int64_t out_stride, int sliding_window, int q_tiles, int num_seqs,
+                         PfContext cx) {
   using M = Mfma<act_t>;
   using frag = typename M::frag;
   constexpr int NT = pf_tiles(HEAD);                 // score tiles per stage
@@ -119,11 +121,18 @@ prefill_attention_kernel(uint16_t* __restrict__ out, const uint16_t* __restrict_
   char* k_img = smem;                                // [kPfBufs][kPfStage][KSTRIDE]
   char* v_img = smem + kPfBufs * kPfStage * KSTRIDE; // [kPfBufs][kPfStage][VSTRIDE]
 
-  const int seq = blockIdx.z;
-  const int head = blockIdx.y;
+  // One workgroup per (query tile, sequence, head), numbered tile-major with the LATEST tiles first: under the
+  // causal mask they have the longest key loops, so the launch's last round is made of the short ones.  Within
+  // a tile index the heads that share a KV head are 8 workgroup numbers apart (workgroups go round-robin over
+  // the 8 XCDs), so that one L2 serves the whole group's reads of its keys and values.
+  const int per_tile = num_heads * num_seqs;
+  const int tile_rank = blockIdx.x / per_tile;
+  const int rem = blockIdx.x - tile_rank * per_tile;
+  const int seq = rem / num_heads;
+  const int hj = rem - seq * num_heads;
+  const int head = (hj % num_kv_heads) * (num_heads / num_kv_heads) + hj / num_kv_heads;
   const int seq_len = seq_lens[seq];
-  // heavy (late) query tiles first: they have the longest key loops under the causal mask
-  const int q_base = (gridDim.x - 1 - blockIdx.x) * WAVES * kPfRows;
+  const int q_base = (q_tiles - 1 - tile_rank) * WAVES * kPfRows;
   if (q_base >= seq_len) return;                     // workgroup-uniform
   const int q0 = q_base + wave * kPfRows;
   const bool active = q0 < seq_len;                  // wave-uniform; idle waves still load tiles and meet barriers
@@ -175,6 +184,37 @@ prefill_attention_kernel(uint16_t* __restrict__ out, const uint16_t* __restrict_
   // that factor, which the fp32 sums and the 16-bit fragments hold without loss (the common factor
   // cancels in the final division).  softmax_exp: the probabilities against `m_ref()`, as B operands
   // of the P.V products (two 16-key fragments per tile), and their sum.
+  // the value held by lane ^ 32 (one v_permlane32_swap; a shuffle through LDS would stall the wave for the
+  // length of an LDS round trip in every stage)
+  auto other_half = [](float x) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float((threadIdx.x & 32) ? r[0] : r[1]);
+  };
+  // S^T = K . Q^T of the NT score tiles of a stage whose K image starts at `kb` (this lane's fragment offset
+  // included).  The tiles' chains of matrix products alternate, and the order of LDS reads and matrix
+  // instructions is pinned: kQkAhead fragments are requested before the first product and one more after each
+  // product, so that a product never waits for a read issued just before it.
+  auto qk_stage = [&](const char* kb, f32x16* sv) {
+    constexpr int NF = NT * KS;
+    constexpr int AHEAD = NF < kQkAhead ? NF : kQkAhead;
+    frag kf[NF];
+#pragma unroll
+    for (int i = 0; i < NF; ++i)
+      kf[i] = *reinterpret_cast<const frag*>(kb + (i % NT) * kPfKeys * KSTRIDE + 32 * (i / NT));
+#pragma unroll
+    for (int u = 0; u < NT; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sv[u][r] = 0.f;
+#pragma unroll
+    for (int i = 0; i < NF; ++i) sv[i % NT] = M::run(kf[i], qf[i / NT], sv[i % NT]);
+    __builtin_amdgcn_sched_group_barrier(0x100, AHEAD, 0);
+#pragma unroll
+    for (int i = 0; i < NF - AHEAD; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, AHEAD, 0);
+  };
   auto tile_max = [&](auto NTC, const f32x16* s) {
     constexpr int NTS = decltype(NTC)::value;
     float m_tile = -INFINITY;
@@ -182,7 +222,7 @@ prefill_attention_kernel(uint16_t* __restrict__ out, const uint16_t* __restrict_
     for (int u = 0; u < NTS; ++u)
 #pragma unroll
       for (int r = 0; r < 16; ++r) m_tile = fmaxf(m_tile, s[u][r]);
-    m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 32, 64));
+    m_tile = fmaxf(m_tile, other_half(m_tile));
     return fmaxf(m_run, m_tile);
   };
   auto wants_rescale = [&](float m_new) { return __builtin_amdgcn_ballot_w64(m_new > m_run + 8.0f) != 0; };
@@ -296,23 +336,7 @@ prefill_attention_kernel(uint16_t* __restrict__ out, const uint16_t* __restrict_
         const char* kb = k_img + cbuf * kPfStage * KSTRIDE + col * KSTRIDE + half * 16;
         const char* vt = v_img + cbuf * kPfStage * VSTRIDE + col * VTS + 8 * half;
         f32x16 sv[NT];
-#pragma unroll
-        for (int u = 0; u < NT; ++u) {
-          f32x16 acc;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-          for (int h0 = 0; h0 < KS; h0 += 4) {
-            frag kf[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-              if (h0 + i < KS) kf[i] = *reinterpret_cast<const frag*>(kb + u * kPfKeys * KSTRIDE + 32 * (h0 + i));
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-              if (h0 + i < KS) acc = M::run(kf[i], qf[h0 + i], acc);
-          }
-          sv[u] = acc;
-        }
+        qk_stage(kb, sv);
 #pragma unroll
         for (int u = 0; u < NT; ++u) {
           const int kt = k0 + u * kPfKeys;
@@ -506,23 +530,6 @@ prefill_attention_kernel(uint16_t* __restrict__ out, const uint16_t* __restrict_
       // compiler answers with scratch memory)
       const char* kb = k_img + buf * kPfStage * KSTRIDE + k_off;
       const char* vb = v_img + buf * kPfStage * VSTRIDE + tr_off;
-      // S^T = K . Q^T of tile u
-      auto qk_tile = [&](int u) {
-        f32x16 acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-        for (int h0 = 0; h0 < KS; h0 += 4) {          // fragments in groups of 4: fewer live registers
-          frag kf[4];
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-            if (h0 + i < KS) kf[i] = *reinterpret_cast<const frag*>(kb + u * kPfKeys * KSTRIDE + 32 * (h0 + i));
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-            if (h0 + i < KS) acc = M::run(kf[i], qf[h0 + i], acc);
-        }
-        return acc;
-      };
       // scale and mask (this lane: query q_idx, keys kt + (r&3) + 8*(r>>2) + 4*half)
       auto mask_scale = [&](f32x16& sc, int kt) {
         if (!needs(kt)) {
@@ -572,8 +579,7 @@ prefill_attention_kernel(uint16_t* __restrict__ out, const uint16_t* __restrict_
       // must then see tile a's products, and the two code arms that takes cost more register copies
       // than the overlap saves: the two waves of a SIMD already fill each other's gaps.)
       f32x16 sv[NT];
-#pragma unroll
-      for (int u = 0; u < NT; ++u) sv[u] = qk_tile(u);
+      qk_stage(kb, sv);
 #pragma unroll
       for (int u = 0; u < NT; ++u) mask_scale(sv[u], k0 + u * kPfKeys);
       frag pt[2 * NT];
@@ -614,7 +620,10 @@ int launch_prefill_w(void* out, const void* q, const void* k, const void* v, con
                      float scale, const float* alibi, int64_t q_stride, int64_t k_stride, int64_t v_stride,
                      int64_t out_stride, int sliding_window, const PfContext& cx, hipStream_t stream) {
   const int rows_per_wg = WAVES * kPfRows;
-  dim3 grid((max_seq_len + rows_per_wg - 1) / rows_per_wg, num_heads, num_seqs);
+  const int q_tiles = (max_seq_len + rows_per_wg - 1) / rows_per_wg;
+  SW_CHECK_ARG((int64_t)q_tiles * num_heads * num_seqs < (int64_t)1 << 31, "prefill attention: %d x %d x %d workgroups",
+               q_tiles, num_heads, num_seqs);
+  dim3 grid((unsigned)(q_tiles * num_heads * num_seqs));
   const size_t smem = (size_t)pf_lds_bytes(HEAD);
   auto kern = prefill_attention_kernel<act_t, HEAD, CTX, WAVES>;
 
@@ -624,21 +633,25 @@ int launch_prefill_w(void* out, const void* q, const void* k, const void* v, con
   kern<<<grid, WAVES * 64, smem, stream>>>(
       static_cast<uint16_t*>(out), static_cast<const uint16_t*>(q), static_cast<const uint16_t*>(k),
       static_cast<const uint16_t*>(v), seq_starts, seq_lens, num_heads, num_kv_heads, scale, alibi, q_stride,
-      k_stride, v_stride, out_stride, sliding_window, cx);
+      k_stride, v_stride, out_stride, sliding_window, q_tiles, num_seqs, cx);
   SW_CHECK_LAUNCH();
   return SW_OK;
 }
 
-// 4 waves (128 query rows) per workgroup, two workgroups per CU; from kPfWideFrom tokens on, without a cached
-// context, 8 waves (256 query rows) share every K / V stage: half the staging traffic per score
-constexpr int kPfWideFrom = 1536;
+// 4 waves (128 query rows) per workgroup, two workgroups per CU.  Without a cached context, prompts of
+// kPfWideFrom tokens or more whose 256-row tiles still make kPfWideWorkgroups workgroups (1.5 per CU) take 8 waves
+// (256 query rows) that share every K / V stage: half the staging traffic per score.  Shorter prompts and
+// smaller launches are faster with the narrow workgroups, which leave fewer CUs idle in the last round.
+constexpr int kPfWideFrom = 2048;
+constexpr int kPfWideWorkgroups = 384;
 
 template <typename act_t, int HEAD, bool CTX>
 int launch_prefill(void* out, const void* q, const void* k, const void* v, const int32_t* seq_starts,
                    const int32_t* seq_lens, int num_seqs, int max_seq_len, int num_heads, int num_kv_heads,
                    float scale, const float* alibi, int64_t q_stride, int64_t k_stride, int64_t v_stride,
                    int64_t out_stride, int sliding_window, const PfContext& cx, hipStream_t stream) {
-  int wide = !CTX && HEAD <= 128 && max_seq_len >= kPfWideFrom;
+  int wide = !CTX && HEAD <= 128 && max_seq_len >= kPfWideFrom &&
+             (int64_t)((max_seq_len + 8 * kPfRows - 1) / (8 * kPfRows)) * num_heads * num_seqs >= kPfWideWorkgroups;
 #ifdef SW_PREFILL_EXPERIMENT
   if (const char* env = getenv("SW_PREFILL_WIDE")) wide = !CTX && HEAD <= 128 && atoi(env) != 0;
 #endif
