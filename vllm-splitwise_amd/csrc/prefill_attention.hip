@@ -215,13 +215,16 @@ prefill_attention_kernel(uint16_t* __restrict__ out, const uint16_t* __restrict_
     }
     __builtin_amdgcn_sched_group_barrier(0x008, AHEAD, 0);
   };
-  auto tile_max = [&](auto NTC, const f32x16* s) {
+  auto tile_max = [&](auto NTC, const f32x16* s, const float* mult) {
     constexpr int NTS = decltype(NTC)::value;
     float m_tile = -INFINITY;
 #pragma unroll
-    for (int u = 0; u < NTS; ++u)
+    for (int u = 0; u < NTS; ++u) {
+      float m_u = s[u][0];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) m_tile = fmaxf(m_tile, s[u][r]);
+      for (int r = 1; r < 16; ++r) m_u = fmaxf(m_u, s[u][r]);
+      m_tile = fmaxf(m_tile, m_u * mult[u]);           // mult > 0: the maximum commutes with it
+    }
     m_tile = fmaxf(m_tile, other_half(m_tile));
     return fmaxf(m_run, m_tile);
   };
@@ -237,27 +240,29 @@ prefill_attention_kernel(uint16_t* __restrict__ out, const uint16_t* __restrict_
   };
   // a query row beyond the sequence (or a fully masked window tile) keeps m at -inf: use 0
   auto m_ref = [&]() { return (m_run == -INFINITY) ? 0.f : m_run; };
-  auto softmax_exp = [&](auto NTC, const f32x16* s, float m_safe, frag* pf) {
+  // Tile u's scores are s[u] * mult[u]: a tile with nothing to mask and no bias keeps the raw products and
+  // mult = the (log2-domain) softmax scale, which then rides in the exponent's multiply-add; a tile that was
+  // scaled, biased or masked element by element comes with mult = 1.
+  auto softmax_exp = [&](auto NTC, const f32x16* s, const float* mult, float m_safe, frag* pf) {
     constexpr int NTS = decltype(NTC)::value;
-    using f32x2 = __attribute__((ext_vector_type(2))) float;
-    const f32x2 m2 = {m_safe, m_safe};
-    f32x2 psum = {0.f, 0.f};                         // (pairs: the subtractions and the sums are packed instructions)
+    float psum0 = 0.f, psum1 = 0.f;
 #pragma unroll
     for (int u = 0; u < NTS; ++u)
 #pragma unroll
       for (int r = 0; r < 16; r += 2) {
-        const f32x2 d = f32x2{s[u][r], s[u][r + 1]} - m2;
-        const f32x2 p = {__builtin_amdgcn_exp2f(d.x), __builtin_amdgcn_exp2f(d.y)};
-        psum += p;
-        pf[2 * u + (r >> 3)][r & 7] = M::cvt(p.x);   // rounded to the activation dtype
-        pf[2 * u + (r >> 3)][(r & 7) + 1] = M::cvt(p.y);
+        const float p0 = __builtin_amdgcn_exp2f(fmaf(s[u][r], mult[u], -m_safe));
+        const float p1 = __builtin_amdgcn_exp2f(fmaf(s[u][r + 1], mult[u], -m_safe));
+        psum0 += p0;
+        psum1 += p1;
+        pf[2 * u + (r >> 3)][r & 7] = M::cvt(p0);      // rounded to the activation dtype
+        pf[2 * u + (r >> 3)][(r & 7) + 1] = M::cvt(p1);
       }
-    l_part += psum.x + psum.y;
+    l_part += psum0 + psum1;
   };
-  auto softmax_step = [&](auto NTC, const f32x16* s, frag* pf) {
-    const float m_new = tile_max(NTC, s);
+  auto softmax_step = [&](auto NTC, const f32x16* s, const float* mult, frag* pf) {
+    const float m_new = tile_max(NTC, s, mult);
     if (wants_rescale(m_new)) rescale(m_new);
-    softmax_exp(NTC, s, m_ref(), pf);
+    softmax_exp(NTC, s, mult, m_ref(), pf);
   };
   using One = std::integral_constant<int, 1>;
 
@@ -337,13 +342,13 @@ prefill_attention_kernel(uint16_t* __restrict__ out, const uint16_t* __restrict_
         const char* vt = v_img + cbuf * kPfStage * VSTRIDE + col * VTS + 8 * half;
         f32x16 sv[NT];
         qk_stage(kb, sv);
+        float mult[NT];
 #pragma unroll
         for (int u = 0; u < NT; ++u) {
           const int kt = k0 + u * kPfKeys;
-          if (kt + kPfKeys <= ctx && slope == 0.f && sliding_window <= 0) {      // wave-uniform: nothing to mask
-#pragma unroll
-            for (int r = 0; r < 16; ++r) sv[u][r] *= scale2;
-          } else {
+          mult[u] = scale2;
+          if (!(kt + kPfKeys <= ctx && slope == 0.f && sliding_window <= 0)) {   // wave-uniform: something to mask
+            mult[u] = 1.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
               const int key = kt + (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -356,7 +361,7 @@ prefill_attention_kernel(uint16_t* __restrict__ out, const uint16_t* __restrict_
           }
         }
         frag pt[2 * NT];
-        softmax_step(std::integral_constant<int, NT>{}, sv, pt);
+        softmax_step(std::integral_constant<int, NT>{}, sv, mult, pt);
         // O^T += V^T . P^T; A operand element j <-> key 16*st + 8*(j>>2) + 4*half + (j&3) of the tile
 #pragma unroll
         for (int u = 0; u < NT; ++u)
@@ -438,7 +443,8 @@ prefill_attention_kernel(uint16_t* __restrict__ out, const uint16_t* __restrict_
         }
       }
       frag pf[2];
-      softmax_step(One{}, &s, pf);
+      const float one = 1.f;
+      softmax_step(One{}, &s, &one, pf);
 #pragma unroll
       for (int st = 0; st < 2; ++st)
 #pragma unroll
@@ -531,30 +537,21 @@ prefill_attention_kernel(uint16_t* __restrict__ out, const uint16_t* __restrict_
       const char* kb = k_img + buf * kPfStage * KSTRIDE + k_off;
       const char* vb = v_img + buf * kPfStage * VSTRIDE + tr_off;
       // scale and mask (this lane: query q_idx, keys kt + (r&3) + 8*(r>>2) + 4*half)
+      // (returns the tile's multiplier, see softmax_exp)
       auto mask_scale = [&](f32x16& sc, int kt) {
-        if (!needs(kt)) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) sc[r] = -INFINITY;
-          return;
-        }
+        const bool wanted = needs(kt);
         const bool need_mask = (kt + kPfKeys - 1 > q0) || (sliding_window > 0);
-        if (!need_mask && slope == 0.f) {                          // wave-uniform: a tile below the diagonal
-#pragma unroll
-          for (int r = 0; r < 16; ++r) sc[r] *= scale2;
-          return;
-        }
+        if (wanted && !need_mask && slope == 0.f) return scale2;     // wave-uniform: a tile below the diagonal
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int key = kt + (r & 3) + 8 * (r >> 2) + 4 * half;
           float x = sc[r] * scale2;
           if (slope != 0.f) x += slope2 * (float)(key - q_idx);
-          if (need_mask) {
-            bool ok = key <= q_idx;
-            if (sliding_window > 0) ok = ok && (q_idx - key < sliding_window);
-            x = ok ? x : -INFINITY;
-          }
-          sc[r] = x;
+          bool ok = wanted && key <= q_idx;
+          if (sliding_window > 0) ok = ok && (q_idx - key < sliding_window);
+          sc[r] = ok ? x : -INFINITY;
         }
+        return 1.f;
       };
       // O^T += V^T . P^T of tile u; A operand element j <-> key 16*st + 8*(j>>2) + 4*half + (j&3)
       auto pv_tile = [&](int u, const frag* pt) {
@@ -580,10 +577,11 @@ prefill_attention_kernel(uint16_t* __restrict__ out, const uint16_t* __restrict_
       // than the overlap saves: the two waves of a SIMD already fill each other's gaps.)
       f32x16 sv[NT];
       qk_stage(kb, sv);
+      float mult[NT];
 #pragma unroll
-      for (int u = 0; u < NT; ++u) mask_scale(sv[u], k0 + u * kPfKeys);
+      for (int u = 0; u < NT; ++u) mult[u] = mask_scale(sv[u], k0 + u * kPfKeys);
       frag pt[2 * NT];
-      softmax_step(std::integral_constant<int, NT>{}, sv, pt);
+      softmax_step(std::integral_constant<int, NT>{}, sv, mult, pt);
 #pragma unroll
       for (int u = 0; u < NT; ++u) pv_tile(u, pt + 2 * u);
     }
