@@ -97,7 +97,7 @@ prefill_attention_kernel(uint16_t* __restrict__ out, const uint16_t* __restrict_
                          const int32_t* __restrict__ seq_starts, const int32_t* __restrict__ seq_lens,
                          int num_heads, int num_kv_heads, float scale,
                          const float* __restrict__ alibi_slopes, int64_t q_stride, int64_t k_stride,
-                         int64_t v_stride, int64_t out_stride, int sliding_window, int q_tiles, int num_seqs,
+                         int64_t v_stride, int64_t out_stride, int sliding_window, int num_seqs,
                          PfContext cx) {
   using M = Mfma<act_t>;
   using frag = typename M::frag;
@@ -132,10 +132,15 @@ prefill_attention_kernel(uint16_t* __restrict__ out, const uint16_t* __restrict_
   const int hj = rem - seq * num_heads;
   const int head = (hj % num_kv_heads) * (num_heads / num_kv_heads) + hj / num_kv_heads;
   const int seq_len = seq_lens[seq];
-  const int q_base = (q_tiles - 1 - tile_rank) * WAVES * kPfRows;
-  if (q_base >= seq_len) return;                     // workgroup-uniform
+  // Query tiles are aligned to the END of the sequence: tile e (from the end) covers the rows
+  // [seq_len - (e+1) R, seq_len - e R), R rows per workgroup, and the sequence's FIRST tile takes what is left.
+  // The remainder rows then sit in the tile with the shortest key loop, not in one that walks all the keys
+  // with most of its waves idle, and every later tile is full.
+  const int q_end = seq_len - tile_rank * WAVES * kPfRows;
+  if (q_end <= 0) return;                            // workgroup-uniform
+  const int q_base = max(0, q_end - WAVES * kPfRows);
   const int q0 = q_base + wave * kPfRows;
-  const bool active = q0 < seq_len;                  // wave-uniform; idle waves still load tiles and meet barriers
+  const bool active = q0 < q_end;                    // wave-uniform; idle waves still load tiles and meet barriers
   const int64_t row0 = seq_starts[seq];
   const int kv_head = head / (num_heads / num_kv_heads);
   const float slope = alibi_slopes ? alibi_slopes[head] : 0.f;
@@ -147,7 +152,7 @@ prefill_attention_kernel(uint16_t* __restrict__ out, const uint16_t* __restrict_
   // ---- Q^T fragments (B operand, natural k order): Q[q][16*ks + 8*half + j]
   frag qf[KS];
   {
-    const int qr = min(q_idx, seq_len - 1);
+    const int qr = min(q_idx, q_end - 1);
     const uint16_t* qp = q + (row0 + qr) * q_stride + (int64_t)head * HEAD + 8 * half;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const frag*>(qp + 16 * ks);
@@ -460,10 +465,10 @@ prefill_attention_kernel(uint16_t* __restrict__ out, const uint16_t* __restrict_
   // ---- phase 2: the new tokens, causal.  The workgroup's 4 waves (128 query rows) share every
   // K / V stage of 64 keys through LDS: global -> registers while the previous stage is being
   // used, registers -> LDS, one barrier per stage.
-  const int k_end = min(q0 + kPfRows, seq_len);      // this wave's keys: < k_end
+  const int k_end = min(q0 + kPfRows, q_end);        // this wave's keys: < k_end
   int k_begin = 0;
   if (sliding_window > 0) k_begin = max(0, (q0 - sliding_window + 1) / kPfKeys * kPfKeys);
-  const int wg_end = min(q_base + WAVES * kPfRows, seq_len);
+  const int wg_end = q_end;
   int wg_begin = 0;
   if (sliding_window > 0) wg_begin = max(0, (q_base - sliding_window + 1) / kPfStage * kPfStage);
 
@@ -542,6 +547,12 @@ prefill_attention_kernel(uint16_t* __restrict__ out, const uint16_t* __restrict_
         const bool wanted = needs(kt);
         const bool need_mask = (kt + kPfKeys - 1 > q0) || (sliding_window > 0);
         if (wanted && !need_mask && slope == 0.f) return scale2;     // wave-uniform: a tile below the diagonal
+        if (slope == 0.f && sliding_window <= 0) {                   // wave-uniform: only the causal mask
+          const int lim = wanted ? q_idx - kt - 4 * half : -1;       // element r is visible iff (r&3) + 8*(r>>2) <= lim
+#pragma unroll
+          for (int r = 0; r < 16; ++r) sc[r] = ((r & 3) + 8 * (r >> 2) <= lim) ? sc[r] : -INFINITY;
+          return scale2;
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int key = kt + (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -593,7 +604,7 @@ prefill_attention_kernel(uint16_t* __restrict__ out, const uint16_t* __restrict_
   // ---- normalise and store: this lane holds query q_idx, O^T rows d = 32*b + (r&3) + 8*(r>>2) + 4*half
   const float l_tot = l_part + __shfl_xor(l_part, 32, 64);
   const float inv = 1.f / l_tot;
-  if (q_idx < seq_len) {
+  if (q_idx < q_end) {
     uint16_t* op = out + (row0 + q_idx) * out_stride + (int64_t)head * HEAD;
 #pragma unroll
     for (int b = 0; b < DB; ++b) {
@@ -631,7 +642,7 @@ int launch_prefill_w(void* out, const void* q, const void* k, const void* v, con
   kern<<<grid, WAVES * 64, smem, stream>>>(
       static_cast<uint16_t*>(out), static_cast<const uint16_t*>(q), static_cast<const uint16_t*>(k),
       static_cast<const uint16_t*>(v), seq_starts, seq_lens, num_heads, num_kv_heads, scale, alibi, q_stride,
-      k_stride, v_stride, out_stride, sliding_window, q_tiles, num_seqs, cx);
+      k_stride, v_stride, out_stride, sliding_window, num_seqs, cx);
   SW_CHECK_LAUNCH();
   return SW_OK;
 }
