@@ -88,7 +88,7 @@ GEMM_SHAPES = [          # (M, K, N, group)
     # the 128-row tile kernel: ragged rows and columns, one and two row tiles, groups of 64 / 128 / 256 / all of k,
     # k split across workgroups (few column tiles) and not (many), and the wide-matrix case from 97 rows on
     (129, 512, 136, 64), (256, 1024, 264, 128), (255, 768, 1024, 256), (192, 2560, 320, 64), (250, 1280, 72, 1280),
-    (160, 256, 3200, 128), (100, 256, 7680, 128),
+    (160, 256, 3200, 128), (100, 256, 7680, 128), (200, 256, 16648, 128),
 ]
 
 

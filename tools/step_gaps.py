@@ -16,8 +16,9 @@ rows.sort()
 # a step = the kernels from one paged-attention layer-0 launch to the next: split at the largest idle gaps instead
 pa = [i for i, r in enumerate(rows) if "paged_attention" in r[2]]
 print(f"{len(rows)} kernels, {len(pa)} decode-attention launches")
-# group paged-attention launches into steps of 32 layers (consecutive launches)
-steps = [pa[i:i + 32] for i in range(0, len(pa) - 31, 32)]
+# group paged-attention launches into steps of `layers` consecutive launches (argv[2], default 32)
+layers = int(sys.argv[2]) if len(sys.argv) > 2 else 32
+steps = [pa[i:i + layers] for i in range(0, len(pa) - layers + 1, layers)]
 best = sorted(steps, key=lambda st: -sum(rows[i][1] - rows[i][0] for i in st))[:8]
 for st in sorted(best):
     lo, hi = st[0], st[-1]

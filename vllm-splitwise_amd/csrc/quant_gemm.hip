@@ -1262,13 +1262,16 @@ static int kmajor_gemm(void* c, const void* a, const uint32_t* qweight, const ui
   float* partials = reinterpret_cast<float*>(ws + kCounterBytes);
   // Kernel choice, from measurements on the 13B / TP2 matrices (tools/quant_exp.hip):
   //   * 128-row tile kernel: more than 128 rows, and 97..128 rows of matrices with 7680 columns or more (it needs
-  //     k in multiples of 256 and groups in multiples of 64);
+  //     k in multiples of 256 and groups in multiples of 64); its tiles are 128 columns wide, 256 when that keeps
+  //     the launch to one round of workgroups (the 27648-column matrix of an unsharded 13B model at 256 rows);
   //   * up to 128 rows otherwise: one row tile per workgroup, k split across its waves;
   //   * 64-row tiled kernel: more than 128 rows of shapes the 128-row kernel does not take.
   int cp = 2, mt = M > 64 ? 4 : M > 32 ? 2 : 1;
   bool tiled = M > 128 && K % kChunkK == 0 && group_size % 16 == 0;
   int waves = 8, chunk = kChunkK, tiled_mt = 2, force_ks = 0;
   int t_variant = (K % 256 == 0 && group_size % 64 == 0 && (M > 128 || (M > 96 && N >= 7680))) ? 4 : 0;
+  // more 128 x 128 tiles than CUs: tiles of 128 x 256 (4 column groups x 2 k parts) do it in one round
+  if (t_variant == 4 && (int64_t)((M + 127) / 128) * ((N + 127) / 128) > 256) t_variant = 2;
 #ifdef SW_QUANT_EXPERIMENT                                     // tuning builds only: never in the shipped library
   if (const char* env = getenv("SW_QUANT_CP")) cp = atoi(env) == 4 ? 4 : 2;
   if (const char* env = getenv("SW_QUANT_MT")) mt = atoi(env);
@@ -1301,8 +1304,8 @@ static int kmajor_gemm(void* c, const void* a, const uint32_t* qweight, const ui
                        qweight, qzeros, sp, M, N, K, group_size, ks, ct, rt, zoff, partials, counters);          \
   } while (0)
     if (t_variant == 4) SW_GPTQ_T128(4, 4, 2, 4, 2);
-#ifdef SW_QUANT_EXPERIMENT
     else if (t_variant == 2) SW_GPTQ_T128(4, 2, 4, 4, 3);
+#ifdef SW_QUANT_EXPERIMENT
     else if (t_variant == 82) SW_GPTQ_T128(8, 2, 2, 4, 2);
     else if (t_variant == 84) SW_GPTQ_T128(8, 4, 1, 2, 2);
 #endif
