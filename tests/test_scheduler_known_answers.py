@@ -1,0 +1,159 @@
+"""Known-answer behaviour of the scheduler, of the sliding-window block accounting and of the small API
+containers: the scenarios and expected answers of the reference's tests/core/test_scheduler.py:11-170
+(admission, abort, prompt-then-decode scheduling, preemption by recomputation followed by an abort,
+the running-sequence cap), tests/core/test_block_manager.py:279-363 (two sequences sharing a sliding
+window), tests/test_sequence.py:21-50 (SamplerOutput as a container) and tests/test_sampling_params.py:6-8,
+restated against this build's classes.  Both scheduler flavours are checked where the scenario does not
+depend on the slot-keeping extension (``strict_reference`` False is this build's default)."""
+import time
+
+import pytest
+
+import conftest  # noqa: F401
+from splitwise_amd.config import CacheConfig, SchedulerConfig
+from splitwise_amd.core.block_manager import BlockSpaceManager
+from splitwise_amd.core.scheduler import Scheduler
+from splitwise_amd.sampling_params import SamplingParams
+from splitwise_amd.sequence import (Logprob, SamplerOutput, Sequence, SequenceGroup, SequenceGroupOutput,
+                                    SequenceOutput)
+
+BLOCK = 4
+
+
+def make_scheduler(max_tokens, max_seqs, max_model_len, blocks, strict):
+    cache = CacheConfig(BLOCK, 1.0, 1, "auto")
+    cache.num_gpu_blocks = blocks
+    cache.num_cpu_blocks = blocks
+    return Scheduler(SchedulerConfig(max_tokens, max_seqs, max_model_len, 256), cache, None, strict_reference=strict)
+
+
+def prompt(request_id, length=BLOCK):
+    seq = Sequence(int(request_id), None, list(range(length)), BLOCK)
+    return seq, SequenceGroup(request_id, [seq], SamplingParams(), time.time())
+
+
+def no_block_moves(out):
+    return not out.blocks_to_copy and not out.blocks_to_swap_in and not out.blocks_to_swap_out
+
+
+@pytest.mark.parametrize("strict", [True, False])
+def test_every_added_group_counts_as_unfinished(strict):
+    sched = make_scheduler(100, 64, 1, 4, strict)
+    for i in range(4):
+        sched.add_seq_group(prompt(str(i))[1])
+        assert sched.get_num_unfinished_seq_groups() == i + 1
+
+
+@pytest.mark.parametrize("strict", [True, False])
+def test_abort_takes_a_set_of_request_ids(strict):
+    sched = make_scheduler(100, 64, 1, 4, strict)
+    ids = {str(i) for i in range(4)}
+    for i in sorted(ids):
+        sched.add_seq_group(prompt(i)[1])
+    assert sched.get_num_unfinished_seq_groups() == 4
+    sched.abort_seq_group(ids)
+    assert sched.get_num_unfinished_seq_groups() == 0
+
+
+@pytest.mark.parametrize("strict", [True, False])
+def test_prompts_go_in_one_step_and_decode_in_the_next(strict):
+    sched = make_scheduler(64, 4, 16, 8, strict)
+    groups = [prompt(str(i))[1] for i in range(4)]
+    for g in groups:
+        sched.add_seq_group(g)
+    metas, out = sched.schedule()                      # the prompt run: all four, 4 tokens each
+    assert set(out.scheduled_seq_groups) == set(groups)
+    assert out.num_batched_tokens == 4 * BLOCK
+    assert no_block_moves(out) and len(metas) == 4
+    metas, out = sched.schedule()                      # one decode token each
+    assert set(out.scheduled_seq_groups) == set(groups)
+    assert out.num_batched_tokens == 4
+    assert no_block_moves(out) and len(metas) == 4
+
+
+@pytest.mark.parametrize("strict", [True, False])
+def test_the_newest_group_is_preempted_for_recomputation_and_returns_after_an_abort(strict):
+    # two blocks in all: both prompts fit, but only one of the sequences can grow into a second block
+    sched = make_scheduler(64, 2, 16, 2, strict)
+    seq_a, group_a = prompt("1")
+    seq_b, group_b = prompt("2")
+    sched.add_seq_group(group_a)
+    sched.add_seq_group(group_b)
+    metas, out = sched.schedule()
+    assert out.scheduled_seq_groups == [group_a, group_b]
+    assert out.num_batched_tokens == 2 * BLOCK and no_block_moves(out) and len(metas) == 2
+    assert sched.get_num_unfinished_seq_groups() == 2
+    for seq in (seq_a, seq_b):
+        seq.append_token_id(0, {0: Logprob(0.0)})
+    metas, out = sched.schedule()                      # b gives its block back, a decodes
+    assert out.scheduled_seq_groups == [group_a]
+    assert out.num_batched_tokens == 1 and no_block_moves(out) and len(metas) == 1
+    assert sched.get_num_unfinished_seq_groups() == 2
+    sched.abort_seq_group("1")
+    metas, out = sched.schedule()                      # b's prompt (now 5 tokens) is computed again
+    assert out.scheduled_seq_groups == [group_b]
+    assert out.num_batched_tokens == seq_b.get_len() and no_block_moves(out) and len(metas) == 1
+    assert sched.get_num_unfinished_seq_groups() == 1
+
+
+@pytest.mark.parametrize("strict", [True, False])
+def test_running_sequences_are_capped_at_max_num_seqs(strict):
+    sched = make_scheduler(64, 2, 16, 8, strict)
+    groups = [prompt(str(i))[1] for i in range(4)]
+    sched.add_seq_group(groups[0])
+    assert set(sched.schedule()[1].scheduled_seq_groups) == {groups[0]}      # its prompt
+    assert set(sched.schedule()[1].scheduled_seq_groups) == {groups[0]}      # its first decode step
+    sched.add_seq_group(groups[1])
+    sched.add_seq_group(groups[2])
+    # one sequence is running, the cap is two: only one of the two new prompts is admitted
+    assert set(sched.schedule()[1].scheduled_seq_groups) == {groups[1]}
+
+
+def test_two_sequences_sharing_a_sliding_window():
+    window, blocks = 2, 8
+    mgr = BlockSpaceManager(1, blocks, blocks, watermark=0, sliding_window=window)
+    assert mgr.get_num_free_gpu_blocks() == blocks
+    parent = Sequence(1, None, [0, 1, 2], 1)
+    mgr.allocate(SequenceGroup("1", [parent], SamplingParams(), time.time()))
+    assert mgr.get_num_free_gpu_blocks() == blocks - window          # three tokens, but the window holds two
+    child = parent.fork(2)
+    mgr.fork(parent, child)
+    assert mgr.get_num_free_gpu_blocks() == blocks - window          # a fork costs nothing
+    assert mgr.get_block_table(parent) == mgr.get_block_table(child)
+    child.append_token_id(4, {4: Logprob(0.0)})
+    mgr.append_slot(child)                                           # the shared block is copied on write
+    assert mgr.get_num_free_gpu_blocks() == blocks - window - 1
+    parent.append_token_id(5, {5: Logprob(0.0)})
+    mgr.append_slot(parent)
+    assert mgr.get_num_free_gpu_blocks() == blocks - window - 1      # still one block shared, one each of their own
+    table_parent, table_child = mgr.get_block_table(parent), mgr.get_block_table(child)
+    assert table_parent != table_child
+    assert table_parent[-2] == table_child[-2]                       # the second-last block is the shared one
+    mgr.free(parent)
+    assert mgr.get_num_free_gpu_blocks() == blocks - window          # the child keeps a full window
+    mgr.free(child)
+    assert mgr.get_num_free_gpu_blocks() == blocks
+
+
+def _group_outputs(n):
+    return [SequenceGroupOutput(samples=[SequenceOutput(parent_seq_id=0, output_token=i, logprobs={})],
+                                prompt_logprobs=None) for i in range(n)]
+
+
+def test_sampler_output_is_a_list_like_container():
+    items = _group_outputs(5)
+    out = SamplerOutput(outputs=items)
+    assert len(out) == 5
+    assert out.sampled_token_probs is None and out.sampled_token_ids is None
+    assert out.spec_decode_worker_metrics is None
+    assert out[2] == items[2]
+    replacement = SequenceGroupOutput(samples=[SequenceOutput(parent_seq_id=0, output_token=99, logprobs={})],
+                                      prompt_logprobs=None)
+    out[2] = replacement
+    assert out[2] == replacement
+    assert SamplerOutput(outputs=_group_outputs(5)) == SamplerOutput(outputs=list(_group_outputs(5)))
+    assert SamplerOutput(outputs=_group_outputs(5)) != SamplerOutput(outputs=_group_outputs(4))
+
+
+def test_sampling_params_accept_no_token_limit():
+    SamplingParams(temperature=0.01, top_p=0.1, max_tokens=None)

@@ -305,12 +305,23 @@ class SequenceGroupOutput:
 class SamplerOutput:
     """One SequenceGroupOutput per scheduled group, list-like (vllm/sequence.py:529-560)."""
     outputs: List[SequenceGroupOutput] = field(default_factory=list)
+    # optional device tensors of a step (token probabilities, sampled ids) and a metrics slot: part of the
+    # reference's data model, left None by this build's sampler
+    sampled_token_probs: Optional[object] = None
+    sampled_token_ids: Optional[object] = None
+    spec_decode_worker_metrics: Optional[object] = None
 
     def __getitem__(self, idx: int) -> SequenceGroupOutput:
         return self.outputs[idx]
 
+    def __setitem__(self, idx: int, value: SequenceGroupOutput) -> None:
+        self.outputs[idx] = value
+
     def __len__(self) -> int:
         return len(self.outputs)
+
+    def __eq__(self, other: object) -> bool:
+        return isinstance(other, self.__class__) and self.outputs == other.outputs
 
     def __iter__(self):
         return iter(self.outputs)
