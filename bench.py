@@ -17,9 +17,12 @@ logs.  Goodput counts the tokens generated inside the timed region by requests t
 the reference's SLO (TTFT <= 0.25 s and mean time between tokens <= 0.1 s).
 
 The run has three phases.  FILL (untimed, independent of --warmup): one request is admitted per
-step until C are in flight, then the loop runs on until every request of that first cohort --
-whose lengths are randomised so that completions do not come in bursts -- has finished; from
-then on every live request has the full shape and the batch is in steady state.  WARMUP: W
+step until C are in flight -- which staggers the requests over about one request lifetime, so that
+completions, and with them prompt arrivals, come at an even rate from then on -- and the loop runs on
+until every request of that first cohort has finished; from then on the batch is in steady state.
+(Giving the first cohort random lengths on top of the staggered admission, as an earlier version did,
+bunches the completions: generated tok/s per 20-step window then swings between 3700 and 7900 over a
+request lifetime instead of 5200-6600; --window-trace prints that series.)  WARMUP: W
 more untimed steps.  TIMED: exactly K steps between device synchronisations.  What the timed
 region actually held (live requests, decode batch sizes, prompt / decode steps) is printed in
 `config`, measured, next to what was asked for.
@@ -76,6 +79,10 @@ def parse_args():
     ap.add_argument("--enforce-eager", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--window-trace", type=int, default=0,
+                    help="print the generated tok/s of every run of this many timed steps (stderr)")
+    ap.add_argument("--first-cohort", default="full", choices=["full", "random", "stratified"],
+                    help="decode lengths of the first C requests: all L (default), random 1..L, or L*(i+1)/C shuffled")
     return ap.parse_args()
 
 
@@ -98,6 +105,10 @@ class ClosedLoop:
         self.first_cohort_live = 0   # requests of the randomised first cohort not finished yet
         self.live_in_window = []     # requests in flight at the start of every timed step
         self.fill_steps = 0
+        self.first_cohort = "full"
+        # one length per slot, evenly spaced over 1..L, in a shuffled order
+        self.cohort_lengths = [max(1, round(decode_len * (i + 1) / concurrency)) for i in range(concurrency)]
+        random.Random(seed + 1).shuffle(self.cohort_lengths)
 
     def _add(self, now):
         from splitwise_amd import SamplingParams
@@ -106,10 +117,15 @@ class ClosedLoop:
         prompt = [self.rng.randrange(self.vocab) for _ in range(self.prompt_len)]
         params = self.params
         if self.next_id <= self.concurrency:
-            # the first cohort gets random lengths so that completions (and hence prompt arrivals)
-            # are spread over time instead of coming in one burst every `decode_len` steps
-            params = SamplingParams(temperature=0.0, max_tokens=self.rng.randint(1, self.params.max_tokens),
-                                    ignore_eos=True)
+            # (optional) other lengths for the first cohort; the staggered admission alone spreads the completions
+            full = self.params.max_tokens
+            if self.first_cohort == "random":
+                n = self.rng.randint(1, full)
+            elif self.first_cohort == "stratified":
+                n = self.cohort_lengths[self.next_id - 1]
+            else:
+                n = full
+            params = SamplingParams(temperature=0.0, max_tokens=n, ignore_eos=True)
         self.engine.add_request(rid, None, params, prompt_token_ids=prompt)
         self.req[rid] = dict(arrival=now, first=None, last=None, n=0, window=0)
         self.live += 1
@@ -155,7 +171,9 @@ class ClosedLoop:
         outs = self.engine.step()
         now = time.perf_counter()
         if in_window:
-            kind = self.step_kinds[had_waiting]
+            # the kind of step the engine scheduled in this call (split pools schedule prompt and decode steps
+            # independently: there a call counts as a prompt step when prompts were waiting)
+            kind = self.step_kinds[bool(getattr(self.engine, "last_scheduled_prompt_run", had_waiting))]
             kind[0] += 1
             kind[1] += now - t_begin
         new_tokens = 0
@@ -300,6 +318,7 @@ def main():
         prefill_batch_tokens=args.prefill_batch_tokens, prefill_max_wait=args.prefill_max_wait,
         pipeline_steps=not args.no_pipeline_steps))
     loop = ClosedLoop(engine, conc, args.prompt_len, args.decode_len, seed=0)
+    loop.first_cohort = args.first_cohort
 
     # decode batches of the timed region: their sizes (all of them) and, for the roofline
     # measurement, the block tables and context lengths of up to 12 spread over the region
@@ -337,10 +356,23 @@ def main():
     state["on"] = True
     t0 = time.perf_counter()
     tokens = 0
+    trace = []                                   # (seconds since t0, tokens so far) after every timed step
     for _ in range(args.steps):
         tokens += loop.step(True)
+        trace.append((time.perf_counter() - t0, tokens))
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    if args.window_trace:
+        # generated tok/s of every run of `window_trace` consecutive steps: how much a short window's figure
+        # depends on where in the request cycle it falls
+        w = args.window_trace
+        rates = []
+        for i in range(w, len(trace) + 1, w):
+            t_a, n_a = trace[i - w - 1] if i > w else (0.0, 0)
+            t_b, n_b = trace[i - 1]
+            rates.append((n_b - n_a) / (t_b - t_a))
+        print(f"tok/s per {w}-step window: " + " ".join(f"{r:.0f}" for r in rates) +
+              f" | min {min(rates):.0f} mean {sum(rates) / len(rates):.0f} max {max(rates):.0f}", file=sys.stderr, flush=True)
     state["on"] = False
 
     good, total, met, seen, ttfts, tpots = loop.goodput_tokens()

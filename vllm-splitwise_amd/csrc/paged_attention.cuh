@@ -162,15 +162,25 @@ paged_attention_kernel(void* __restrict__ out_,            // v1: [S,H,HEAD]; v2
   // the same block table and the same cache blocks (a block holds its heads side by side), so
   // they are renumbered to run on ONE XCD, next to each other in time: its L2 and its address
   // translation then see each block of the sequence once, not once per XCD (2-3 % on launches
-  // of thousands of workgroups; small launches keep the plain order).
+  // of thousands of workgroups; small launches keep the plain order).  XCD x takes the sequences x, x + 8,
+  // x + 16, ... when their number is a multiple of 8 -- not a contiguous eighth of the batch: batches are
+  // often ordered by age, hence by length, and a contiguous eighth would hand one XCD all the long contexts
+  // (a length-sorted long-tailed batch ran at half the bandwidth that way).
   int seq = blockIdx.y, hx = blockIdx.x;
   {
     const int total = gridDim.x * gridDim.y;
     if ((total & 7) == 0 && total >= 1024) {
       const int lin = blockIdx.y * gridDim.x + blockIdx.x;
-      const int work = (lin & 7) * (total >> 3) + (lin >> 3);
-      seq = work / (int)gridDim.x;
-      hx = work - seq * (int)gridDim.x;
+      if ((gridDim.y & 7) == 0) {
+        const int local = lin >> 3;                          // this XCD's local-th workgroup
+        const int local_seq = local / (int)gridDim.x;
+        hx = local - local_seq * (int)gridDim.x;
+        seq = local_seq * 8 + (lin & 7);
+      } else {
+        const int work = (lin & 7) * (total >> 3) + (lin >> 3);
+        seq = work / (int)gridDim.x;
+        hx = work - seq * (int)gridDim.x;
+      }
     }
   }
   const int part_idx = blockIdx.z;

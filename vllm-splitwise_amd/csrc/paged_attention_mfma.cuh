@@ -97,9 +97,16 @@ paged_attention_mfma_kernel(void* __restrict__ out_, float* __restrict__ exp_sum
     const int total = gridDim.x * gridDim.y;
     if ((total & 7) == 0 && total >= 1024) {
       const int lin = blockIdx.y * gridDim.x + blockIdx.x;
-      const int work = (lin & 7) * (total >> 3) + (lin >> 3);
-      seq = work / (int)gridDim.x;
-      hx = work - seq * (int)gridDim.x;
+      if ((gridDim.y & 7) == 0) {                            // XCD x: sequences x, x + 8, ... (not a contiguous eighth)
+        const int local = lin >> 3;
+        const int local_seq = local / (int)gridDim.x;
+        hx = local - local_seq * (int)gridDim.x;
+        seq = local_seq * 8 + (lin & 7);
+      } else {
+        const int work = (lin & 7) * (total >> 3) + (lin >> 3);
+        seq = work / (int)gridDim.x;
+        hx = work - seq * (int)gridDim.x;
+      }
     }
   }
   const int part_idx = blockIdx.z;

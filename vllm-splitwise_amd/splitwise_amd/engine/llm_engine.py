@@ -351,6 +351,7 @@ class LLMEngine:
 
     def _step_pipelined(self) -> List[RequestOutput]:
         metas, scheduler_outputs = self.scheduler.schedule()
+        self.last_scheduled_prompt_run = bool(scheduler_outputs.prompt_run) and not scheduler_outputs.is_empty()
         launched = None
         if not scheduler_outputs.is_empty():
             pairs = [(g, g.get_seqs(status=SequenceStatus.RUNNING)[0])
@@ -377,6 +378,7 @@ class LLMEngine:
         if self.pipeline_steps:
             return self._step_pipelined()
         metas, scheduler_outputs = self.scheduler.schedule()
+        self.last_scheduled_prompt_run = bool(scheduler_outputs.prompt_run) and not scheduler_outputs.is_empty()
         if not scheduler_outputs.is_empty():
             output = self.model_executor.execute_model(
                 metas, scheduler_outputs.blocks_to_swap_in, scheduler_outputs.blocks_to_swap_out,
