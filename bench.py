@@ -359,7 +359,7 @@ def main():
     trace = []                                   # (seconds since t0, tokens so far) after every timed step
     for _ in range(args.steps):
         tokens += loop.step(True)
-        trace.append((time.perf_counter() - t0, tokens))
+        trace.append((time.perf_counter() - t0, tokens, bool(getattr(engine, "last_scheduled_prompt_run", False))))
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if args.window_trace:
@@ -368,11 +368,18 @@ def main():
         w = args.window_trace
         rates = []
         for i in range(w, len(trace) + 1, w):
-            t_a, n_a = trace[i - w - 1] if i > w else (0.0, 0)
-            t_b, n_b = trace[i - 1]
+            t_a, n_a = trace[i - w - 1][:2] if i > w else (0.0, 0)
+            t_b, n_b = trace[i - 1][:2]
             rates.append((n_b - n_a) / (t_b - t_a))
         print(f"tok/s per {w}-step window: " + " ".join(f"{r:.0f}" for r in rates) +
               f" | min {min(rates):.0f} mean {sum(rates) / len(rates):.0f} max {max(rates):.0f}", file=sys.stderr, flush=True)
+        if len(trace) <= 60:                     # every step: kind scheduled in the call, tokens returned, host time
+            prev_t, prev_n = 0.0, 0
+            parts = []
+            for t, n, prompt in trace:
+                parts.append(f"{'P' if prompt else 'D'}{n - prev_n}:{(t - prev_t) * 1e3:.0f}ms")
+                prev_t, prev_n = t, n
+            print("steps: " + " ".join(parts), file=sys.stderr, flush=True)
     state["on"] = False
 
     good, total, met, seen, ttfts, tpots = loop.goodput_tokens()

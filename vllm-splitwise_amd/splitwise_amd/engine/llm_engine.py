@@ -4,6 +4,8 @@ API and step structure of vllm/engine/llm_engine.py:150-633 (from_engine_args, a
 abort_request, step, has_unfinished_requests); stop logic of _check_stop (:755-784).  Beam
 search and n > 1 forking are outside this build (one sequence per request).
 """
+import gc
+import os
 import time
 from typing import Dict, Iterable, List, Optional, Union
 
@@ -67,6 +69,13 @@ class LLMEngine:
         self._free_later: List[Sequence] = []
         if self.pipeline_split:
             self.scheduler.in_flight = self._seq_in_flight
+        # Everything built so far (modules, parameters, captured graphs, block tables) lives as long as the engine
+        # does.  Python's cyclic collector would walk all of it on every full collection -- tens of milliseconds
+        # in the middle of a serving loop, 4 % of the closed-loop benchmark's throughput -- so those objects are
+        # moved out of its reach; what the steps allocate from now on is collected as usual.
+        if os.environ.get("SPLITWISE_FREEZE_GC", "1") != "0":
+            gc.collect()
+            gc.freeze()
 
     def _seq_in_flight(self, seq: Sequence) -> bool:
         """Pipelined split pools: is the sequence part of a prompt step or a decode step that has been

@@ -1,4 +1,6 @@
 """The command loop of a worker that lives in another process (the token worker of a split pair)."""
+import gc
+import os
 import traceback
 from typing import Any, Dict
 
@@ -36,9 +38,16 @@ def worker_loop(channel, cfg: Dict[str, Any], worker_cls=Worker) -> None:
                             kv_transport_init=transport_init, **extra)
         reports = cfg.get("reports_output", True)      # tensor-parallel followers compute but do not report
         pending = None                                  # samples of a deferred step that have not been reported yet
+        frozen = os.environ.get("SPLITWISE_FREEZE_GC", "1") == "0"
         while True:
             msg = channel.recv()
             cmd, args = msg[0], msg[1:]
+            if not frozen and cmd in ("execute", "execute_deferred"):
+                # set-up is over (model, cache, captured graphs): keep the cyclic collector away from those
+                # long-lived objects, as the engine does on its side
+                gc.collect()
+                gc.freeze()
+                frozen = True
             if cmd == "shutdown":
                 channel.send(("ok", None))
                 break
