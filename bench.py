@@ -14,15 +14,17 @@ A *step* is one engine iteration: one scheduling decision plus one pass of the h
 kept in flight (a finished request is replaced at once), each with a 772-token synthetic
 prompt and 170 generated tokens -- the mean request shape of the reference's own benchmark
 logs.  Goodput counts the tokens generated inside the timed region by requests that meet
-the reference's SLO (TTFT <= 0.25 s and mean time between tokens <= 0.1 s).
+the reference's SLO (TTFT <= 0.25 s and mean time between tokens <= 0.1 s).  With pipelined steps
+a call returns the tokens of the step launched one call earlier; the region is credited with the
+tokens of the steps that RAN in it: not those of a step that finished before it began (returned by
+its first call), but those of the step still in flight when its closing synchronisation ends.
 
-The run has three phases.  FILL (untimed, independent of --warmup): one request is admitted per
-step until C are in flight -- which staggers the requests over about one request lifetime, so that
-completions, and with them prompt arrivals, come at an even rate from then on -- and the loop runs on
-until every request of that first cohort has finished; from then on the batch is in steady state.
-(Giving the first cohort random lengths on top of the staggered admission, as an earlier version did,
-bunches the completions: generated tok/s per 20-step window then swings between 3700 and 7900 over a
-request lifetime instead of 5200-6600; --window-trace prints that series.)  WARMUP: W
+The run has three phases.  FILL (untimed, independent of --warmup): C / L requests are admitted per
+decode step (C in flight, L generated tokens each: the steady state's own admission rate) until C are in
+flight, and the loop runs on until every request of that first cohort has finished; completions, and with
+them prompt arrivals, then come at an even rate.  (--window-trace prints generated tok/s per run of steps:
+earlier fill rules -- one admission per engine step, random lengths for the first cohort -- left a dense
+stretch of arrivals that the closed loop replays once per request lifetime.)  WARMUP: W
 more untimed steps.  TIMED: exactly K steps between device synchronisations.  What the timed
 region actually held (live requests, decode batch sizes, prompt / decode steps) is printed in
 `config`, measured, next to what was asked for.
@@ -106,6 +108,9 @@ class ClosedLoop:
         self.live_in_window = []     # requests in flight at the start of every timed step
         self.fill_steps = 0
         self.first_cohort = "full"
+        self.credit = 1.0            # admissions owed during the ramp (the first request enters at once)
+        self.window_debt = {}        # request id -> tokens of steps launched before the timed region
+        self.last_was_decode = True  # did the engine's last call schedule a decode step (or nothing)?
         # one length per slot, evenly spaced over 1..L, in a shuffled order
         self.cohort_lengths = [max(1, round(decode_len * (i + 1) / concurrency)) for i in range(concurrency)]
         random.Random(seed + 1).shuffle(self.cohort_lengths)
@@ -133,12 +138,20 @@ class ClosedLoop:
             self.first_cohort_live += 1
 
     def feed(self):
-        """One new request per step while ramping up (so no request queues behind a burst),
-        then one per finished request."""
+        """While ramping up: C / L new requests per DECODE step (C requests in flight, L generated tokens
+        each) -- the admission rate of the steady state itself, in which every decode step retires C / L
+        requests on average.  The first request then finishes just as the C-th is admitted, and from there on
+        each finished request is replaced at once: completions, and with them prompt arrivals, keep the even
+        spacing of the ramp.  (One admission per engine step, as an earlier version did, packs the early
+        admissions more densely than the late ones, and every request lifetime later the loop runs through
+        the same dense stretch again.)"""
         now = time.perf_counter()
-        if self.ramp < self.concurrency:
-            self.ramp += 1
-            self._add(now)
+        if self.ramp < self.concurrency and self.last_was_decode:
+            self.credit += self.concurrency / self.params.max_tokens
+            while self.credit >= 1.0 and self.ramp < self.concurrency:
+                self.credit -= 1.0
+                self.ramp += 1
+                self._add(now)
         while self.live < min(self.ramp, self.concurrency):
             self._add(now)
 
@@ -162,6 +175,39 @@ class ClosedLoop:
         lv = self.live_in_window
         return {"live_min": min(lv) if lv else 0, "live_mean": round(sum(lv) / max(len(lv), 1), 1)}
 
+    def inflight_requests(self):
+        """Request ids of the sequences in steps that the engine has launched and not collected yet (pipelined
+        engines; empty otherwise).  Each of them gets one token from that step."""
+        eng = self.engine
+        ids = []
+        if getattr(eng, "_inflight", None) is not None:
+            ids += [group.request_id for group, _ in eng._inflight[2]]
+        if getattr(eng, "_decode_inflight", None) is not None:
+            ids += [group.request_id for group, _ in eng._decode_inflight[1]]
+        if getattr(eng, "_prompt_inflight", None) is not None:
+            ids += list(eng._prompt_inflight[2])
+        return ids
+
+    def open_window(self):
+        """Call at the start of the timed region, after the device synchronisation.  With pipelined steps the
+        first timed call returns the tokens of steps that were launched -- and, because of the synchronisation,
+        finished -- BEFORE the region began: those tokens are not the region's work."""
+        self.window_debt = {}
+        for rid in self.inflight_requests():
+            self.window_debt[rid] = self.window_debt.get(rid, 0) + 1
+
+    def close_window(self):
+        """Call at the end of the timed region, after the device synchronisation: the steps still in flight ran
+        inside the region, so their tokens (one per sequence) are the region's work although no call has
+        returned them yet.  Returns their number."""
+        n = 0
+        for rid in self.inflight_requests():
+            r = self.req.get(rid)
+            if r is not None:
+                r["window"] += 1
+                n += 1
+        return n
+
     def step(self, in_window):
         self.feed()
         if in_window:
@@ -170,6 +216,7 @@ class ClosedLoop:
         had_waiting = bool(self.engine.scheduler.waiting)
         outs = self.engine.step()
         now = time.perf_counter()
+        self.last_was_decode = not getattr(self.engine, "last_scheduled_prompt_run", False)
         if in_window:
             # the kind of step the engine scheduled in this call (split pools schedule prompt and decode steps
             # independently: there a call counts as a prompt step when prompts were waiting)
@@ -181,9 +228,16 @@ class ClosedLoop:
             r = self.req[out.request_id]
             n = len(out.outputs[0].token_ids)
             if n > r["n"]:
-                new_tokens += n - r["n"]
+                fresh = n - r["n"]
                 if in_window:
-                    r["window"] += n - r["n"]
+                    owed = min(fresh, self.window_debt.get(out.request_id, 0))      # launched before the window
+                    if owed:
+                        self.window_debt[out.request_id] -= owed
+                    fresh_in_window = fresh - owed
+                    r["window"] += fresh_in_window
+                    new_tokens += fresh_in_window
+                else:
+                    new_tokens += fresh
                 r["n"] = n
                 if r["first"] is None:
                     r["first"] = now
@@ -354,6 +408,7 @@ def main():
         loop.step(False)
     torch.cuda.synchronize()
     state["on"] = True
+    loop.open_window()
     t0 = time.perf_counter()
     tokens = 0
     trace = []                                   # (seconds since t0, tokens so far) after every timed step
@@ -362,6 +417,7 @@ def main():
         trace.append((time.perf_counter() - t0, tokens, bool(getattr(engine, "last_scheduled_prompt_run", False))))
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    tokens += loop.close_window()
     if args.window_trace:
         # generated tok/s of every run of `window_trace` consecutive steps: how much a short window's figure
         # depends on where in the request cycle it falls

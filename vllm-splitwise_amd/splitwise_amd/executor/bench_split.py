@@ -116,6 +116,7 @@ def _run(args, rank: int, local_rank: int, world: int) -> None:
     torch.cuda.synchronize()
     if engines is not None:
         dist.barrier(group=engines)
+    loop.open_window()                   # tokens of steps launched before this point are not the region's
     t0 = time.perf_counter()
     ctx_samples = []
     stride = max(1, args.steps // 12)
@@ -133,6 +134,7 @@ def _run(args, rank: int, local_rank: int, world: int) -> None:
     if engines is not None:
         dist.barrier(group=engines)
     elapsed = time.perf_counter() - t0
+    loop.close_window()                  # ... and the steps still in flight ran inside it
 
     good, total, met, seen, ttfts, tpots = loop.goodput_tokens()
     win = loop.window_stats()
