@@ -63,6 +63,37 @@ def test_greedy_generation_matches_cpu_model(model, enforce_eager):
     torch.cuda.empty_cache()
 
 
+@pytest.mark.parametrize("enforce_eager,pipeline", [(True, False), (False, False), (False, True)])
+def test_ragged_decode_batches_run_longest_first_and_report_in_request_order(enforce_eager, pipeline):
+    """Decode batches whose longest context is well above the mean are run longest context first; requests still
+    get their own tokens (against the CPU model), in the plain loop, with captured graphs and with pipelined steps
+    (where the next step reads this step's tokens on the device, by sequence)."""
+    from splitwise_amd import LLM, SamplingParams
+    random.seed(5)
+    llm = LLM("llama-tiny", enforce_eager=enforce_eager, num_gpu_blocks_override=256, max_num_seqs=16,
+              max_model_len=512, swap_space=0.01, pipeline_steps=pipeline)
+    runner = llm.llm_engine.model_executor.driver_worker.model_runner
+    runner.sort_decode_min_batch = 2
+    calls = []
+    plain = runner._longest_first
+
+    def watched(metas):
+        restore = plain(metas)
+        calls.append(restore is not None)
+        return restore
+
+    runner._longest_first = watched
+    vocab = llm.llm_engine.model_config.get_vocab_size()
+    prompts = [[random.randrange(vocab) for _ in range(n)] for n in (4, 9, 300, 6, 12, 3, 250, 8, 5, 200)]
+    outs = llm.generate(prompt_token_ids=prompts, sampling_params=SamplingParams(temperature=0.0, max_tokens=12))
+    assert any(calls), "no decode batch was reordered"
+    assert [o.request_id for o in outs] == [str(i) for i in range(len(prompts))]
+    assert all(len(o.outputs[0].token_ids) == 12 for o in outs)
+    _check_greedy(llm, prompts, outs, tol=3e-2)
+    del llm
+    torch.cuda.empty_cache()
+
+
 def test_opt_125m_geometry_greedy_generation_matches_cpu_model():
     """The reference's own CPU-runnable case (examples/offline_inference.py: OPT-125m, greedy): the full geometry --
     12 layers, 768 hidden, 12 heads of 64, vocabulary 50272, learned positions -- with random weights, eager and

@@ -76,6 +76,7 @@ class PendingSamples:
                 self.row_of[seq_id] = len(self.row_of)
         self.event = None
         self.after_sync = []         # callables run by resolve() once the step has finished on the device
+        self._report_order = None    # see reorder()
         if next_ids.is_cuda:
             self._ids = torch.empty(next_ids.shape, dtype=next_ids.dtype, pin_memory=True)
             self._ids.copy_(next_ids, non_blocking=True)
@@ -102,8 +103,17 @@ class PendingSamples:
         checks, self.after_sync = self.after_sync, []
         for check in checks:         # e.g. the worker's look at its hand-off / all-reduce status words
             check()
-        return _build_output(self.seq_groups, self._ids.tolist(), None if self._lp is None else self._lp.tolist(),
-                             None if self._top is None else tuple(t.tolist() for t in self._top))
+        out = _build_output(self.seq_groups, self._ids.tolist(), None if self._lp is None else self._lp.tolist(),
+                            None if self._top is None else tuple(t.tolist() for t in self._top))
+        if self._report_order is not None:
+            out.reorder(self._report_order)
+        return out
+
+    def reorder(self, positions: List[int]) -> None:
+        """The step ran its sequence groups in another order than it was asked for: ``positions[i]`` is where
+        group i of the request sits in ``seq_groups``.  ``resolve`` reports in the requested order; ``row_of``
+        and ``next_ids`` keep the order the step ran in (the next step looks rows up by sequence id)."""
+        self._report_order = positions
 
 
 class Sampler(nn.Module):

@@ -323,6 +323,11 @@ class SamplerOutput:
     def __eq__(self, other: object) -> bool:
         return isinstance(other, self.__class__) and self.outputs == other.outputs
 
+    def reorder(self, positions: List[int]) -> None:
+        """``positions[i]`` = where the i-th group of the caller's order sits in ``outputs`` (a step may run its
+        groups in an order of its own)."""
+        self.outputs = [self.outputs[p] for p in positions]
+
     def __iter__(self):
         return iter(self.outputs)
 

@@ -286,6 +286,7 @@ class ModelRunner:
         """``defer``: return the step's ``PendingSamples`` (tokens still on the device) instead of a
         ``SamplerOutput``; the next decode step takes unknown last tokens from it."""
         is_prompt = metas[0].is_prompt
+        restore = None
         if is_prompt:
             if prompt_layout == "packed":
                 tokens, positions, md, prompt_lens, starts = self._prepare_prompt_packed(metas)
@@ -296,6 +297,9 @@ class ModelRunner:
                 last_rows = [i * width + n - 1 for i, n in enumerate(prompt_lens)]
             sampling_md = self._prepare_sample(metas, last_rows)
         else:
+            restore = self._longest_first(metas)
+            if restore is not None:
+                metas = [metas[i] for i in restore[0]]
             tokens, positions, md = self._prepare_decode(metas)
             sampling_md = self._prepare_sample(metas, None)
         md.blocks_to_nw = blocks_to_nw or {}
@@ -306,8 +310,36 @@ class ModelRunner:
             hidden = self.model(tokens.view(-1), positions.view(-1), kv_caches, md)
         sampling_md.defer = defer
         result = self.model.sample(hidden, sampling_md)
+        if not is_prompt and restore is not None and result is not None:
+            result.reorder(restore[1])           # report in the order the step was asked for
         self.pending = result if defer else None
         return result
+
+    # a decode batch is reordered when it has at least this many sequences and its longest context is this many
+    # times the mean
+    sort_decode_min_batch = 16
+    sort_decode_min_ratio = 1.5
+
+    def _longest_first(self, metas: List[SequenceGroupMetadata]):
+        """-> (order, inverse) to run a ragged decode batch longest context first, or None to leave it alone.
+        The decode-attention kernels start their workgroups in batch order, and an unpartitioned workgroup walks
+        one sequence's whole context: a long context at the END of the batch starts last and finishes long after
+        everything else (6 sequences of 6000 tokens behind 250 of 600: 582 us against 516 us the other way
+        round).  Nothing else in a step depends on the order of its rows; the samples are put back into the
+        order of ``metas`` before they are reported."""
+        n = len(metas)
+        if n < self.sort_decode_min_batch or any(len(m.seq_data) != 1 for m in metas):
+            return None
+        lens = [next(iter(m.seq_data.values())).get_len() for m in metas]
+        if max(lens) * n < self.sort_decode_min_ratio * sum(lens):
+            return None
+        order = sorted(range(n), key=lambda i: -lens[i])          # stable: equal lengths keep their order
+        if order == list(range(n)):
+            return None
+        inverse = [0] * n
+        for pos, i in enumerate(order):
+            inverse[i] = pos
+        return order, inverse
 
     @torch.inference_mode()
     def profile_run(self) -> None:
