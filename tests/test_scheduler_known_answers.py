@@ -157,3 +157,18 @@ def test_sampler_output_is_a_list_like_container():
 
 def test_sampling_params_accept_no_token_limit():
     SamplingParams(temperature=0.01, top_p=0.1, max_tokens=None)
+
+
+def test_decode_kernel_choice_takes_raggedness_into_account():
+    """v1 (one workgroup per sequence and head group) against v2 (512-token partitions): short contexts and large
+    launches stay unpartitioned; a launch of a few hundred workgroups whose longest context is at least twice the
+    mean goes partitioned when the mean is known (eager steps)."""
+    from splitwise_amd.model_executor.layers.attention import PagedAttentionImpl
+    use_v1 = PagedAttentionImpl.use_v1
+    assert use_v1(256, 32, 32, 500)                                    # one partition: nothing to split
+    assert use_v1(256, 32, 32, 8192)                                   # 8192 workgroups
+    assert use_v1(256, 32, 32, 8192, 1, mean_context_len=1000.0)       # ... ragged or not
+    assert use_v1(256, 16, 2, 8192, 8)                                 # 512 matrix-core workgroups, mean unknown
+    assert not use_v1(256, 16, 2, 8192, 8, mean_context_len=1009.0)    # the same launch, known to be ragged
+    assert use_v1(256, 16, 2, 8192, 8, mean_context_len=7000.0)        # long but even
+    assert use_v1(64, 64, 8, 900, 8, mean_context_len=100.0)           # ragged but short: two partitions at most

@@ -19,3 +19,5 @@ class InputMetadata:
     kv_cache_dtype: str
     # {hand-off slot: [(first block, number of blocks), ...]} to push (prompt pool) or await (token pool)
     blocks_to_nw: Dict[int, List[Tuple[int, int]]] = field(default_factory=dict)
+    # mean context of an eagerly run decode step (None: unknown, e.g. inside a captured graph)
+    mean_context_len: Optional[float] = None

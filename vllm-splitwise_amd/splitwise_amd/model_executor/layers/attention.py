@@ -56,7 +56,8 @@ class PagedAttentionImpl:
         return min(width, cap)
 
     @staticmethod
-    def use_v1(num_seqs: int, num_heads: int, num_kv_heads: int, max_context_len: int, query_group: int = 1) -> bool:
+    def use_v1(num_seqs: int, num_heads: int, num_kv_heads: int, max_context_len: int, query_group: int = 1,
+               mean_context_len: Optional[float] = None) -> bool:
         """The unpartitioned kernel launches one workgroup per (sequence, group of ``query_group``
         query heads); it fills the 256 CUs only with enough of them, below that the context is
         split into 512-token partitions (v2).  Thresholds measured on MI355X for MHA, GQA and fp8
@@ -67,6 +68,14 @@ class PagedAttentionImpl:
         if max_context_len <= _PARTITION_SIZE:
             return True
         workgroups = num_seqs * num_heads // max(query_group, 1)
+        # A ragged batch (longest context at least twice the mean, when the caller knows the mean): an
+        # unpartitioned workgroup walks the longest context alone while the rest of a launch of a few hundred
+        # workgroups has long finished; 512-token partitions spread it (16/2 heads, 256 sequences, mean 1009, max
+        # 8192 tokens: 119 us unpartitioned, 67 us partitioned).  Launches of thousands of workgroups keep the
+        # unpartitioned kernel: there the long ones overlap with the many short ones that follow.
+        if (mean_context_len is not None and max_context_len >= 2 * mean_context_len
+                and max_context_len > 2 * _PARTITION_SIZE and workgroups < 2048):
+            return False
         if query_group >= 4:
             # the matrix-core kernel (8 waves per workgroup below 256 workgroups): unpartitioned from 128
             # workgroups, and for short contexts whatever the launch size
@@ -101,7 +110,8 @@ class PagedAttentionImpl:
         max_ctx = input_metadata.max_context_len
         width = PagedAttentionImpl.query_group_width(num_heads, num_kv_heads, head_size, block_size, query.dtype,
                                                      input_metadata.kv_cache_dtype)
-        if PagedAttentionImpl.use_v1(num_seqs, num_heads, num_kv_heads, max_ctx, width):
+        if PagedAttentionImpl.use_v1(num_seqs, num_heads, num_kv_heads, max_ctx, width,
+                                     getattr(input_metadata, "mean_context_len", None)):
             _C.ops.paged_attention_v1(output, query, key_cache, value_cache, num_kv_heads, scale,
                                       input_metadata.block_tables, input_metadata.context_lens, block_size,
                                       max_ctx, alibi_slopes, input_metadata.kv_cache_dtype)

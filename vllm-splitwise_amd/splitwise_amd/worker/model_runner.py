@@ -234,7 +234,8 @@ class ModelRunner:
             prompt_lens=None, max_seq_len=None, start_loc=None, max_context_len=max_ctx,
             context_lens=self._to_device(np.asarray(context_lens, dtype=np.int32), torch.int32),
             block_tables=self._to_device(_pad_2d(tables, width, 0, np.int32), torch.int32),
-            use_cuda_graph=use_graph, kv_cache_dtype=self.kv_cache_dtype)
+            use_cuda_graph=use_graph, kv_cache_dtype=self.kv_cache_dtype,
+            mean_context_len=None if use_graph else sum(context_lens) / batch)
         token_tensor = self._to_device(np.asarray(tokens, dtype=np.int64).reshape(-1, 1), torch.long)
         if any(r >= 0 for r in from_pending):
             src = self._to_device(np.asarray(from_pending, dtype=np.int64), torch.long)
