@@ -172,3 +172,25 @@ def test_decode_kernel_choice_takes_raggedness_into_account():
     assert not use_v1(256, 16, 2, 8192, 8, mean_context_len=1009.0)    # the same launch, known to be ragged
     assert use_v1(256, 16, 2, 8192, 8, mean_context_len=7000.0)        # long but even
     assert use_v1(64, 64, 8, 900, 8, mean_context_len=100.0)           # ragged but short: two partitions at most
+
+
+def test_ragged_decode_batches_are_ordered_longest_first_and_mapped_back():
+    from splitwise_amd.sequence import SequenceData, SequenceGroupMetadata
+    from splitwise_amd.worker.model_runner import ModelRunner
+    runner = ModelRunner.__new__(ModelRunner)            # only the ordering rule is exercised
+
+    def metas(lens):
+        return [SequenceGroupMetadata(str(i), False, {i: SequenceData(list(range(n)))}, SamplingParams(), {i: [0]})
+                for i, n in enumerate(lens)]
+
+    assert runner._longest_first(metas([100] * 32)) is None                     # even lengths: left alone
+    assert runner._longest_first(metas([100] * 8 + [5000])) is None             # small batch: left alone
+    lens = [50] * 20 + [4000, 60, 3000] + [40] * 9
+    order, inverse = runner._longest_first(metas(lens))
+    assert [lens[i] for i in order] == sorted(lens, reverse=True)
+    assert order[:2] == [20, 22] and order[2] == 21                              # stable among equal lengths
+    assert all(order[inverse[i]] == i for i in range(len(lens)))
+    out = SamplerOutput(outputs=[SequenceGroupOutput([SequenceOutput(i, i, {})], None) for i in order])
+    out.reorder(inverse)                                                         # back to the order asked for
+    assert [g.samples[0].parent_seq_id for g in out] == list(range(len(lens)))
+    assert runner._longest_first(metas(sorted(lens, reverse=True))) is None      # already longest first
