@@ -146,3 +146,29 @@ def test_chunked_prompt_equals_whole_prompt():
                                  torch.tensor([first], device="cuda"), total - first)
     torch.cuda.synchronize()
     torch.testing.assert_close(part.float(), whole[first:].float(), atol=2e-3, rtol=1e-3)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_seeded_random_launches_over_a_cached_prefix(seed):
+    """Random launches: 1-5 sequences, new-token runs of 1-400 tokens (query tiles are aligned to the end of each
+    run), cached prefixes of 0-600 tokens, block sizes 8 / 16 / 32, grouped-query layouts, ALiBi or a window."""
+    rng = random.Random(200 + seed)
+    dtype = rng.choice([torch.float16, torch.bfloat16])
+    head = rng.choice([64, 128, 128])
+    block_size = rng.choice([8, 16, 32])
+    per_kv = rng.choice([1, 2, 4])
+    heads = per_kv * rng.choice([1, 2, 3])
+    n = rng.randint(1, 5)
+    pool = [1, 31, 32, 33, 64, 65, 127, 128, 129, 255, 257, 385]
+    new_lens = [rng.choice(pool) if rng.random() < 0.6 else rng.randint(1, 400) for _ in range(n)]
+    ctx_lens = [rng.choice([0, 1, 63, 64, 65, 200, 511]) if rng.random() < 0.6 else rng.randint(0, 600) for _ in range(n)]
+    variant = rng.choice(["plain", "plain", "alibi", "window"])
+    s = head ** -0.5
+    q, k, v, kc, vc, table = _case(heads, per_kv, head, dtype, block_size, new_lens, ctx_lens, scale_inputs=s,
+                                   seed=300 + seed)
+    alibi = torch.randn(heads, dtype=torch.float) * 0.05 if variant == "alibi" else None
+    window = rng.choice([40, 130, 500]) if variant == "window" else None
+    out = _run(q, k, v, kc, vc, table, new_lens, ctx_lens, alibi, window)
+    ref = oattn.context_attention(q, k, v, kc, vc, table, new_lens, ctx_lens, alibi, window)
+    assert not torch.isnan(out.float()).any()
+    torch.testing.assert_close(out.float(), ref.float(), atol=1e-3, rtol=1e-2)

@@ -102,6 +102,32 @@ def test_long_prompts_take_the_256_row_workgroups(dtype, variant):
     torch.testing.assert_close(out.cpu().float(), ref.float(), atol=1e-3, rtol=1e-5)
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_seeded_random_ragged_launches(seed):
+    """Random launches: 1-7 prompts of 1-900 tokens (lengths around the 128-row tiles, the 64-key stages and
+    their remainders), grouped-query layouts, head sizes, ALiBi or a sliding window -- every query tile is aligned
+    to the end of its prompt, so each length exercises another split of rows into tiles."""
+    rng = random.Random(100 + seed)
+    torch.manual_seed(seed)
+    dtype = rng.choice([torch.float16, torch.bfloat16])
+    head_size = rng.choice([64, 128, 128, 96])
+    kvh = rng.choice([1, 2, 4])
+    h = kvh * rng.choice([1, 2, 4])
+    pool = [1, 2, 31, 32, 33, 63, 64, 65, 127, 128, 129, 191, 192, 193, 255, 256, 257, 384, 385, 511, 513, 640, 772, 900]
+    seq_lens = [rng.choice(pool) if rng.random() < 0.6 else rng.randint(1, 900) for _ in range(rng.randint(1, 7))]
+    variant = rng.choice(["plain", "plain", "alibi", "window"])
+    n = sum(seq_lens)
+    scale = float(head_size ** -0.5)
+    qkv = torch.empty(n, h + 2 * kvh, head_size, dtype=dtype).uniform_(-scale, scale)
+    q, k, v = qkv.split([h, kvh, kvh], dim=1)
+    alibi = torch.randn(h, dtype=torch.float) * 0.05 if variant == "alibi" else None
+    window = rng.choice([17, 64, 100, 300]) if variant == "window" else None
+    ref = oattn.prefill_attention(q, k, v, seq_lens, scale, alibi, window)
+    qd, kd, vd = qkv.cuda().split([h, kvh, kvh], dim=1)
+    out = run(qd, kd, vd, seq_lens, scale, alibi.cuda() if alibi is not None else None, window=window)
+    torch.testing.assert_close(out.cpu().float(), ref.float(), atol=1e-3, rtol=1e-5)
+
+
 def test_float32_is_rejected():
     from splitwise_amd import _C
     q = torch.zeros(4, 2, 64, device="cuda")
