@@ -118,6 +118,36 @@ def test_paged_attention_other_layouts(version, dtype, block_size, head_size, he
     torch.testing.assert_close(out.cpu().float(), ref.float(), atol=atol, rtol=1e-5)
 
 
+@pytest.mark.parametrize("version", ["v1", "v2"])
+@pytest.mark.parametrize("heads,num_seqs,dtype,kv_cache_dtype", [
+    ((16, 16), 64, torch.bfloat16, "auto"), ((16, 16), 72, torch.float16, "fp8_e5m2"),
+    ((64, 8), 128, torch.float16, "auto"), ((64, 8), 128, torch.bfloat16, "fp8_e5m2"),
+    ((16, 16), 65, torch.bfloat16, "auto")])
+def test_large_launches_with_length_sorted_ragged_contexts(version, heads, num_seqs, dtype, kv_cache_dtype):
+    """Launches of a thousand workgroups and more renumber their workgroups so that a sequence's heads share an
+    XCD (XCD x: sequences x, x + 8, ... when the batch is a multiple of 8; a contiguous range otherwise -- the
+    65-sequence case).  Contexts from 1 token to 1200, sorted by length as an age-ordered batch would be, both
+    kernels, vector and matrix-core paths, against the oracle."""
+    random.seed(2)
+    torch.manual_seed(2)
+    h, kvh = heads
+    head_size, block_size, nb = 128, 16, 2048
+    scale = float(head_size ** -0.5)
+    query = torch.empty(num_seqs, h, head_size, dtype=dtype).uniform_(-scale, scale)
+    lens = sorted([1, 2, 15, 16, 17, 511, 512, 513, 1200] + [random.randint(1, 1200) for _ in range(num_seqs - 9)],
+                  reverse=True)
+    max_blocks = (max(lens) + block_size - 1) // block_size
+    block_tables = torch.tensor([[random.randint(0, nb - 1) for _ in range(max_blocks)] for _ in range(num_seqs)],
+                                dtype=torch.int)
+    context_lens = torch.tensor(lens, dtype=torch.int)
+    kc, vc = make_kv_caches(nb, block_size, kvh, head_size, dtype, cache_dtype=kv_cache_dtype)
+    ref = oattn.paged_attention(query, kc, vc, block_tables, context_lens, scale, None)
+    out = run_kernel(version, query.cuda(), kc.cuda(), vc.cuda(), kvh, scale, block_tables.cuda(),
+                     context_lens.cuda(), block_size, None, kv_cache_dtype)
+    atol = 1e-2 if kv_cache_dtype == "fp8_e5m2" else 1e-3
+    torch.testing.assert_close(out.cpu().float(), ref.float(), atol=atol, rtol=1e-5)
+
+
 def test_strided_query_and_nan_tail():
     """The query is a slice of a fused qkv tensor (q_stride != H*D), and the unused tail of
     the last block holds NaNs that must not leak (attention_kernels.cu:342-351)."""
