@@ -24,6 +24,9 @@ class LLMEngine:
                  scheduler_config: SchedulerConfig, device_config: DeviceConfig, executor_class=None,
                  log_stats: bool = False, tokenizer=None, num_gpu_blocks_override: Optional[int] = None,
                  executor=None) -> None:
+        self._freeze_gc = os.environ.get("SPLITWISE_FREEZE_GC", "1") != "0"
+        if self._freeze_gc:
+            gc.unfreeze()       # what an earlier engine of this process froze may be garbage by now (see the end)
         self.model_config = model_config
         self.cache_config = cache_config
         self.parallel_config = parallel_config
@@ -73,7 +76,7 @@ class LLMEngine:
         # does.  Python's cyclic collector would walk all of it on every full collection -- tens of milliseconds
         # in the middle of a serving loop, 4 % of the closed-loop benchmark's throughput -- so those objects are
         # moved out of its reach; what the steps allocate from now on is collected as usual.
-        if os.environ.get("SPLITWISE_FREEZE_GC", "1") != "0":
+        if self._freeze_gc:
             gc.collect()
             gc.freeze()
 
