@@ -94,6 +94,29 @@ def test_ragged_decode_batches_run_longest_first_and_report_in_request_order(enf
     torch.cuda.empty_cache()
 
 
+def test_ragged_batches_replay_the_graph_with_the_partitioned_decode_kernel():
+    """Batch sizes for which the dispatch rule takes the unpartitioned decode kernel at the capture's maximum
+    context, but would partition a ragged batch, are captured in both forms; a batch of 120 short and 8 long
+    contexts replays the partitioned form, and every request still gets the tokens the CPU model gives."""
+    from splitwise_amd import LLM, SamplingParams
+    random.seed(11)
+    llm = LLM("llama-tiny", enforce_eager=False, num_gpu_blocks_override=2048, max_num_seqs=128, max_model_len=2048,
+              max_num_batched_tokens=4096, swap_space=0.01)
+    runner = llm.llm_engine.model_executor.driver_worker.model_runner
+    assert 128 in runner.graph_runners_partitioned and 8 not in runner.graph_runners_partitioned
+    vocab = llm.llm_engine.model_config.get_vocab_size()
+    lens = [random.randint(4, 40) for _ in range(120)] + [1100 + 7 * i for i in range(8)]
+    random.shuffle(lens)
+    prompts = [[random.randrange(vocab) for _ in range(n)] for n in lens]
+    outs = llm.generate(prompt_token_ids=prompts, sampling_params=SamplingParams(temperature=0.0, max_tokens=6))
+    assert sum(r.replays for r in runner.graph_runners_partitioned.values()) > 0
+    assert all(len(o.outputs[0].token_ids) == 6 for o in outs)
+    picked = [i for i, n in enumerate(lens) if n > 1000] + list(range(0, 120, 10))
+    _check_greedy(llm, [prompts[i] for i in picked], [outs[i] for i in picked], tol=3e-2)
+    del llm
+    torch.cuda.empty_cache()
+
+
 def test_opt_125m_geometry_greedy_generation_matches_cpu_model():
     """The reference's own CPU-runnable case (examples/offline_inference.py: OPT-125m, greedy): the full geometry --
     12 layers, 768 hidden, 12 heads of 64, vocabulary 50272, learned positions -- with random weights, eager and

@@ -21,3 +21,6 @@ class InputMetadata:
     blocks_to_nw: Dict[int, List[Tuple[int, int]]] = field(default_factory=dict)
     # mean context of an eagerly run decode step (None: unknown, e.g. inside a captured graph)
     mean_context_len: Optional[float] = None
+    # "v1" / "v2": the decode-attention kernel to use whatever the dispatch rule says (captured graphs exist in
+    # both forms and the runner picks one per replay); None: the rule decides
+    decode_kernel: Optional[str] = None

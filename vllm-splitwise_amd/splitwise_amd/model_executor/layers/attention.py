@@ -110,8 +110,13 @@ class PagedAttentionImpl:
         max_ctx = input_metadata.max_context_len
         width = PagedAttentionImpl.query_group_width(num_heads, num_kv_heads, head_size, block_size, query.dtype,
                                                      input_metadata.kv_cache_dtype)
-        if PagedAttentionImpl.use_v1(num_seqs, num_heads, num_kv_heads, max_ctx, width,
-                                     getattr(input_metadata, "mean_context_len", None)):
+        forced = getattr(input_metadata, "decode_kernel", None)
+        if forced is not None:
+            unpartitioned = forced == "v1"
+        else:
+            unpartitioned = PagedAttentionImpl.use_v1(num_seqs, num_heads, num_kv_heads, max_ctx, width,
+                                                      getattr(input_metadata, "mean_context_len", None))
+        if unpartitioned:
             _C.ops.paged_attention_v1(output, query, key_cache, value_cache, num_kv_heads, scale,
                                       input_metadata.block_tables, input_metadata.context_lens, block_size,
                                       max_ctx, alibi_slopes, input_metadata.kv_cache_dtype)

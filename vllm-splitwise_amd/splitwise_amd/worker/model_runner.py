@@ -67,6 +67,8 @@ class ModelRunner:
         self.model = None
         self.block_size: Optional[int] = None
         self.graph_runners: Dict[int, "HIPGraphRunner"] = {}
+        # batch sizes that were also captured with the partitioned decode-attention kernel (see capture_model)
+        self.graph_runners_partitioned: Dict[int, "HIPGraphRunner"] = {}
         self.graph_memory_pool = None
         self.max_context_len_to_capture = model_config.max_context_len_to_capture if model_config else 0
         self.enforce_eager = model_config.enforce_eager if model_config is not None else True
@@ -236,6 +238,12 @@ class ModelRunner:
             block_tables=self._to_device(_pad_2d(tables, width, 0, np.int32), torch.int32),
             use_cuda_graph=use_graph, kv_cache_dtype=self.kv_cache_dtype,
             mean_context_len=None if use_graph else sum(context_lens) / batch)
+        if use_graph and padded in self.graph_runners_partitioned:
+            # this batch size was captured with either decode-attention kernel (the rule picked the unpartitioned one
+            # for the capture's maximum context): a ragged batch replays the partitioned form
+            real = context_lens[:batch]
+            if not self._decode_rule(batch, max(real), sum(real) / batch):
+                md.decode_kernel = "v2"
         token_tensor = self._to_device(np.asarray(tokens, dtype=np.int64).reshape(-1, 1), torch.long)
         if any(r >= 0 for r in from_pending):
             src = self._to_device(np.asarray(from_pending, dtype=np.int64), torch.long)
@@ -306,7 +314,8 @@ class ModelRunner:
         md.blocks_to_nw = blocks_to_nw or {}
         # the model sees one flat token dimension in every layout
         if md.use_cuda_graph:
-            hidden = self.graph_runners[tokens.shape[0]](tokens, positions, kv_caches, md)
+            runners = self.graph_runners_partitioned if md.decode_kernel == "v2" else self.graph_runners
+            hidden = runners[tokens.shape[0]](tokens, positions, kv_caches, md)
         else:
             hidden = self.model(tokens.view(-1), positions.view(-1), kv_caches, md)
         sampling_md.defer = defer
@@ -315,6 +324,16 @@ class ModelRunner:
             result.reorder(restore[1])           # report in the order the step was asked for
         self.pending = result if defer else None
         return result
+
+    def _decode_rule(self, num_seqs: int, max_ctx: int, mean_ctx: Optional[float]) -> bool:
+        """PagedAttentionImpl.use_v1 for this model's attention geometry."""
+        from ..model_executor.layers.attention import PagedAttentionImpl
+        tp = self.parallel_config.tensor_parallel_size
+        heads = self.model_config.hf_config["num_attention_heads"] // tp
+        kv_heads = self.model_config.get_num_kv_heads(self.parallel_config)
+        width = PagedAttentionImpl.query_group_width(heads, kv_heads, self.model_config.get_head_size(), self.block_size,
+                                                     self.model_config.dtype, self.kv_cache_dtype)
+        return PagedAttentionImpl.use_v1(num_seqs, heads, kv_heads, max_ctx, width, mean_ctx)
 
     # a decode batch is reordered when it has at least this many sequences and its longest context is this many
     # times the mean
@@ -385,6 +404,17 @@ class ModelRunner:
             runner.capture(tokens[:bs], positions[:bs], kv_caches, md, self.graph_memory_pool)
             self.graph_memory_pool = runner.graph.pool()
             self.graph_runners[bs] = runner
+            if (self._decode_rule(bs, self.max_context_len_to_capture, None)
+                    and not self._decode_rule(bs, self.max_context_len_to_capture, 1.0)):
+                # The rule takes the unpartitioned kernel for this launch but would partition a ragged batch of
+                # the same size: a second graph with the partitioned kernel, same static buffers.
+                md2 = InputMetadata(is_prompt=False, slot_mapping=slots[:bs], prompt_lens=None, max_seq_len=None,
+                                    start_loc=None, max_context_len=self.max_context_len_to_capture,
+                                    context_lens=context_lens[:bs], block_tables=block_tables[:bs],
+                                    use_cuda_graph=True, kv_cache_dtype=self.kv_cache_dtype, decode_kernel="v2")
+                second = HIPGraphRunner(self.model)
+                second.capture(tokens[:bs], positions[:bs], kv_caches, md2, self.graph_memory_pool)
+                self.graph_runners_partitioned[bs] = second
         self.capture_seconds = time.perf_counter() - t0
 
 
@@ -396,6 +426,7 @@ class HIPGraphRunner:
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self.inputs: Dict[str, torch.Tensor] = {}
         self.output: Optional[torch.Tensor] = None
+        self.replays = 0
 
     def capture(self, tokens, positions, kv_caches, md: InputMetadata, pool) -> None:
         assert self.graph is None
@@ -418,4 +449,5 @@ class HIPGraphRunner:
         self.inputs["context_lens"].copy_(md.context_lens, non_blocking=True)
         self.inputs["block_tables"].copy_(md.block_tables, non_blocking=True)
         self.graph.replay()
+        self.replays += 1
         return self.output
