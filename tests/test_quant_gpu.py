@@ -248,3 +248,39 @@ def test_awq_argument_checks_mirror_the_reference():
     x = torch.zeros((1, 128), dtype=torch.float16, device="cuda")
     with pytest.raises(ValueError, match="cta_N"):
         _C.ops.awq_gemm(x, _dev(qweight), _dev(scales), _dev(qzeros), 8)
+
+
+def test_int4_layers_keep_their_fp16_weight_for_many_row_calls():
+    """Above the fused kernels' row limit a layer reconstructs its weight and runs a dense GEMM; the
+    reconstruction is kept (within a per-process budget), so the second call of a layer does no reconstruction
+    and gives the same bits as the first and as the operator that reconstructs on every call."""
+    from splitwise_amd import _C
+    from splitwise_amd.model_executor.layers.quantization import dense_copy
+    from splitwise_amd.model_executor.layers.quantization.gptq import ExllamaState, GPTQConfig, GPTQLinearMethod
+    k, n, group, m = 512, 384, 128, 300
+    qweight, qzeros, scales, _ = _gptq_case(k, n, group, 21)
+    x = _dev(np.random.default_rng(5).standard_normal((m, k)).astype(np.float16))
+    method = GPTQLinearMethod(GPTQConfig(4, group, False))
+    weights = {name: torch.nn.Parameter(_dev(t), requires_grad=False)
+               for name, t in (("qweight", qweight), ("qzeros", qzeros), ("scales", scales))}
+    weights["g_idx"] = torch.nn.Parameter(torch.arange(k, dtype=torch.int32, device="cuda") // group, requires_grad=False)
+    weights["exllama_state"] = ExllamaState.UNINITIALIZED
+    used = dense_copy._used_bytes
+    first = method.apply_weights(weights, x)
+    assert dense_copy._used_bytes == used + k * n * 2 and weights["_dense_copy"].shape == (k, n)
+    calls = []
+    plain = _C.ops.dequant_gptq
+    _C.ops.dequant_gptq = lambda *a: calls.append(1) or plain(*a)
+    try:
+        second = method.apply_weights(weights, x)
+    finally:
+        _C.ops.dequant_gptq = plain
+    assert not calls and torch.equal(first, second)
+    direct = _C.ops.gptq_gemm(x, weights["qweight"], weights["qzeros"], weights["scales"], weights["g_idx"], True, 4)
+    assert torch.equal(first, direct)
+    small = method.apply_weights(weights, x[:7])                    # few rows: the fused int4 kernel, as before
+    torch.testing.assert_close(small.float(), first[:7].float(), atol=2e-2, rtol=1e-2)
+    del weights, first, second
+    import gc
+    gc.collect()
+    assert dense_copy._used_bytes == used                           # the budget comes back with the layer

@@ -7,6 +7,7 @@ from torch.nn.parameter import Parameter
 from .... import _C
 from ..linear import LinearMethodBase, set_weight_attrs
 from .base_config import QuantizationConfig
+from .dense_copy import dense_weight
 
 
 class AWQConfig(QuantizationConfig):
@@ -87,7 +88,15 @@ class AWQLinearMethod(LinearMethodBase):
             if not weights.get("_kmajor"):
                 qweight.data, qzeros.data = _C.ops.awq_to_kmajor(qweight.data, qzeros.data)
                 weights["_kmajor"] = True
-            out = _C.ops.int4_kmajor_gemm(reshaped_x, qweight, qzeros, scales, 0)
+            dense = None
+            if reshaped_x.shape[0] > _C.GPTQ_FUSED_MAX_ROWS:
+                # many rows: reconstruct + dense GEMM, as ops.int4_kmajor_gemm does -- with the reconstruction kept
+                dense = dense_weight(weights, reshaped_x.shape[-1], qweight.shape[-1],
+                                     lambda: _C.ops.int4_kmajor_dequant(qweight, qzeros, scales, 0))
+            if dense is not None:
+                out = torch.matmul(reshaped_x, dense)
+            else:
+                out = _C.ops.int4_kmajor_gemm(reshaped_x, qweight, qzeros, scales, 0)
             if bias is not None:
                 out = out + bias
             return out.reshape(x.shape[:-1] + (qweight.shape[-1],))

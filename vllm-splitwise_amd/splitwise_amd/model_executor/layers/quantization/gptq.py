@@ -12,6 +12,7 @@ from torch.nn.parameter import Parameter
 from .... import _C
 from ..linear import LinearMethodBase, set_weight_attrs
 from .base_config import QuantizationConfig
+from .dense_copy import dense_weight
 
 
 class GPTQConfig(QuantizationConfig):
@@ -110,9 +111,18 @@ class GPTQLinearMethod(LinearMethodBase):
                 weights["g_idx"] = torch.empty((1, 1), device="meta")
             weights["exllama_state"] = ExllamaState.READY
             _C.ops.gptq_shuffle(weights["qweight"], weights["g_idx"], self.quant_config.weight_bits)
-        output = _C.ops.gptq_gemm(reshaped_x, weights["qweight"], weights["qzeros"], weights["scales"],
-                                  weights["g_idx"], weights["exllama_state"] == ExllamaState.READY,
-                                  self.quant_config.weight_bits)
+        ready = weights["exllama_state"] == ExllamaState.READY
+        dense = None
+        if reshaped_x.shape[0] > _C.GPTQ_FUSED_MAX_ROWS and reshaped_x.is_cuda:
+            # many rows: reconstruct + dense GEMM, as ops.gptq_gemm does -- with the reconstruction kept
+            dense = dense_weight(weights, reshaped_x.shape[-1], qweight.shape[-1],
+                                 lambda: _C.ops.dequant_gptq(weights["qweight"], weights["qzeros"], weights["scales"],
+                                                             weights["g_idx"], self.quant_config.weight_bits, ready))
+        if dense is not None:
+            output = torch.matmul(reshaped_x, dense)
+        else:
+            output = _C.ops.gptq_gemm(reshaped_x, weights["qweight"], weights["qzeros"], weights["scales"],
+                                      weights["g_idx"], ready, self.quant_config.weight_bits)
         if bias is not None:
             output = output + bias
         return output.reshape(out_shape)
