@@ -194,3 +194,26 @@ def test_ragged_decode_batches_are_ordered_longest_first_and_mapped_back():
     out.reorder(inverse)                                                         # back to the order asked for
     assert [g.samples[0].parent_seq_id for g in out] == list(range(len(lens)))
     assert runner._longest_first(metas(sorted(lens, reverse=True))) is None      # already longest first
+
+
+def test_dense_copies_of_int4_weights_respect_the_budget(monkeypatch):
+    import gc
+    import torch
+    from splitwise_amd.model_executor.layers.quantization import dense_copy
+    monkeypatch.setattr(dense_copy, "_BUDGET_BYTES", dense_copy._used_bytes + 3000)
+    made = []
+
+    def reconstruct():
+        made.append(1)
+        return torch.zeros(32, 32, dtype=torch.float16)              # 2048 bytes
+
+    layer_a, layer_b = {}, {}
+    w = dense_copy.dense_weight(layer_a, 32, 32, reconstruct)
+    assert w is not None and dense_copy.dense_weight(layer_a, 32, 32, reconstruct) is w and len(made) == 1
+    assert dense_copy.dense_weight(layer_b, 32, 32, reconstruct) is None            # 4096 bytes would exceed the budget
+    assert dense_copy.dense_weight(layer_b, 32, 32, reconstruct) is None and len(made) == 1
+    used = dense_copy._used_bytes
+    del w
+    layer_a.clear()
+    gc.collect()
+    assert dense_copy._used_bytes == used - 2048                                     # given back with the layer
