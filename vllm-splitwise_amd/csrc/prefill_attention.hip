@@ -97,7 +97,7 @@ prefill_attention_kernel(uint16_t* __restrict__ out, const uint16_t* __restrict_
                          const int32_t* __restrict__ seq_starts, const int32_t* __restrict__ seq_lens,
                          int num_heads, int num_kv_heads, float scale,
                          const float* __restrict__ alibi_slopes, int64_t q_stride, int64_t k_stride,
-                         int64_t v_stride, int64_t out_stride, int sliding_window, int num_seqs,
+                         int64_t v_stride, int64_t out_stride, int sliding_window, int num_seqs, int max_seq_len,
                          PfContext cx) {
   using M = Mfma<act_t>;
   using frag = typename M::frag;
@@ -136,7 +136,12 @@ prefill_attention_kernel(uint16_t* __restrict__ out, const uint16_t* __restrict_
   // [seq_len - (e+1) R, seq_len - e R), R rows per workgroup, and the sequence's FIRST tile takes what is left.
   // The remainder rows then sit in the tile with the shortest key loop, not in one that walks all the keys
   // with most of its waves idle, and every later tile is full.
-  const int q_end = seq_len - tile_rank * WAVES * kPfRows;
+  // Workgroup rank r (0 = first to start) holds, of every sequence, the tile whose end is r tiles before the end of
+  // the LONGEST sequence of the launch: a short sequence's tiles start when the long ones' tiles of the same key
+  // count do, so that ragged launches too begin with their heaviest tiles.
+  const int tile_e = tile_rank - (max_seq_len - seq_len) / (WAVES * kPfRows);
+  if (tile_e < 0) return;                            // workgroup-uniform
+  const int q_end = seq_len - tile_e * WAVES * kPfRows;
   if (q_end <= 0) return;                            // workgroup-uniform
   const int q_base = max(0, q_end - WAVES * kPfRows);
   const int q0 = q_base + wave * kPfRows;
@@ -642,7 +647,7 @@ int launch_prefill_w(void* out, const void* q, const void* k, const void* v, con
   kern<<<grid, WAVES * 64, smem, stream>>>(
       static_cast<uint16_t*>(out), static_cast<const uint16_t*>(q), static_cast<const uint16_t*>(k),
       static_cast<const uint16_t*>(v), seq_starts, seq_lens, num_heads, num_kv_heads, scale, alibi, q_stride,
-      k_stride, v_stride, out_stride, sliding_window, num_seqs, cx);
+      k_stride, v_stride, out_stride, sliding_window, num_seqs, max_seq_len, cx);
   SW_CHECK_LAUNCH();
   return SW_OK;
 }
