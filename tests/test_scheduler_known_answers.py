@@ -217,3 +217,54 @@ def test_dense_copies_of_int4_weights_respect_the_budget(monkeypatch):
     layer_a.clear()
     gc.collect()
     assert dense_copy._used_bytes == used - 2048                                     # given back with the layer
+
+
+@pytest.mark.parametrize("split", [False, True])
+def test_a_prompt_that_extends_an_earlier_output_shares_only_blocks_a_prompt_step_wrote(split):
+    """Prefix caching, multi-turn: request B's prompt is request A's prompt plus A's generated text.  Co-located,
+    every full block of A (prompt and decode) is in the one cache and may be reported as computed.  With split
+    pools the blocks that filled up during A's decode steps hold KV on the token pool only: B's prompt worker
+    must compute them itself, so they may be neither shared by content nor reported as computed."""
+    cache = CacheConfig(BLOCK, 1.0, 1, "auto", enable_prefix_caching=True)
+    cache.num_gpu_blocks = cache.num_cpu_blocks = 32
+    sched = Scheduler(SchedulerConfig(64, 8, 64, 256), cache, None, track_prompt_blocks=split)
+    seq_a = Sequence(0, None, list(range(100, 100 + 2 * BLOCK)), BLOCK)             # two full prompt blocks
+    group_a = SequenceGroup("a", [seq_a], SamplingParams(), time.monotonic())
+    sched.add_seq_group(group_a)
+
+    def engine_marks(group, prompt_run):          # what LLMEngine._process_model_outputs does after a step
+        if prompt_run or not split:
+            sched.mark_blocks_as_computed(group)
+
+    metas, out = (sched.schedule_prompts() if split else sched.schedule())
+    assert out.prompt_run and len(metas) == 1
+    engine_marks(group_a, True)
+    if split:
+        sched.prompt_step_done(["a"])
+    generated = []
+    for step in range(2 * BLOCK + 1):             # A's first token comes from the prompt step; then 2 blocks more
+        tok = 500 + step
+        generated.append(tok)
+        seq_a.append_token_id(tok, {tok: Logprob(0.0)})
+        metas, out = (sched.schedule_decodes() if split else sched.schedule())
+        assert not out.prompt_run and len(metas) == 1
+        engine_marks(group_a, False)
+    table_a = sched.block_manager.get_block_table(seq_a)
+    assert len(table_a) == 5
+    # B = A's prompt + A's output so far + one new block of its own
+    seq_b = Sequence(1, None, list(range(100, 100 + 2 * BLOCK)) + generated + [900 + i for i in range(BLOCK)], BLOCK)
+    group_b = SequenceGroup("b", [seq_b], SamplingParams(), time.monotonic())
+    sched.add_seq_group(group_b)
+    metas, out = (sched.schedule_prompts() if split else sched.schedule())
+    assert out.prompt_run and [m.request_id for m in metas] == ["b"]
+    table_b = sched.block_manager.get_block_table(seq_b)
+    computed = metas[0].computed_block_nums
+    if split:
+        # only A's prompt-step blocks are shared and computed: the first of its two prompt blocks is reported
+        # (the reference never marks the last full block of a step), nothing written by a decode step is
+        assert table_b[:2] == table_a[:2]
+        assert not set(table_b[2:]) & set(table_a[2:])
+        assert computed == table_a[:1]
+    else:
+        assert table_b[:4] == table_a[:4]
+        assert computed == table_a[:len(computed)] and len(computed) >= 3

@@ -553,12 +553,10 @@ int launch_pa_mfma_nw(const PaArgs& a, int qg, dim3 grid) {
   const size_t smem = (size_t)NW * kPaMfmaHeads * kPaMfmaPRow * 2 + (size_t)NW * qg * HEAD * 4 + 2 * NW * qg * 4;
   auto kernel = paged_attention_mfma_kernel<act_t, FP8, HEAD, BS, NW>;
   if (smem > 64 * 1024) {
-    static bool raised = false;             // per instantiation: the attribute sticks to the function
-    if (!raised) {
-      SW_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-      raised = true;
-    }
+    // on every launch: the attribute belongs to the function ON THE CURRENT DEVICE, and a process may drive
+    // several devices from several threads; the call costs well under a microsecond
+    SW_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
   }
   kernel<<<grid, NW * 64, smem, a.stream>>>(
       a.partitioned ? a.tmp_out : a.out, a.exp_sums, a.max_logits, a.q, a.k, a.v, a.num_heads, a.num_kv_heads,

@@ -186,6 +186,10 @@ class BlockSpaceManager:
         self.cpu_allocator = pool(Device.CPU, block_size, num_cpu_blocks)
         self.block_tables: Dict[int, List[int]] = {}
         self._on_cpu: set = set()            # seq ids whose table holds CPU block numbers
+        # Blocks that fill up during DECODE steps become shareable by content (see _maybe_promote_last_block).
+        # With split pools their KV exists on the token pool only, so a later prompt that shared them would
+        # have its prompt worker read blocks that were never written there: the scheduler turns this off.
+        self.promote_decode_blocks = True
 
     # ------------------------------------------------------------------ prompts
     def can_allocate(self, seq_group: SequenceGroup) -> AllocStatus:
@@ -231,13 +235,13 @@ class BlockSpaceManager:
         if not self.enable_caching:
             return self.gpu_allocator.allocate()
         last = seq.num_logical_blocks - 1
-        block_hash = seq.hash_of_block(last) if self._is_last_block_full(seq) else None
+        block_hash = seq.hash_of_block(last) if self._is_last_block_full(seq) and self.promote_decode_blocks else None
         return self.gpu_allocator.allocate(block_hash, seq.num_hashed_tokens_of_block(last))
 
     def _maybe_promote_last_block(self, seq: Sequence, block: int) -> int:
         """A block that has just become full gets its content hash, so that other sequences can share it;
         if a block with that content exists already, that one is used instead (block_manager.py:218-252)."""
-        if not self.enable_caching or not self._is_last_block_full(seq):
+        if not self.enable_caching or not self.promote_decode_blocks or not self._is_last_block_full(seq):
             return block
         new_hash = seq.hash_of_block(seq.num_logical_blocks - 1)
         if self.gpu_allocator.contains_block(new_hash):

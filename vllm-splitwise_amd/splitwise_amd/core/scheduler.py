@@ -85,6 +85,9 @@ class Scheduler:
             block_size=cache_config.block_size, num_gpu_blocks=cache_config.num_gpu_blocks,
             num_cpu_blocks=cache_config.num_cpu_blocks, sliding_window=cache_config.sliding_window,
             enable_caching=cache_config.enable_prefix_caching)
+        # split pools: only blocks written by a PROMPT step exist on both pools (the decode steps' KV lives on
+        # the token pool alone), so only those may be shared with later prompts
+        self.block_manager.promote_decode_blocks = not track_prompt_blocks
         self.waiting: Deque[SequenceGroup] = deque()
         self.running: Deque[SequenceGroup] = deque()
         self.swapped: Deque[SequenceGroup] = deque()
@@ -361,9 +364,6 @@ class Scheduler:
 
     def free_finished_seq_groups(self) -> None:
         self.running = deque(g for g in self.running if not g.is_finished())
-
-    def mark_blocks_as_computed(self, seq_group: SequenceGroup) -> None:
-        self.block_manager.mark_blocks_as_computed(seq_group)
 
     def _allocate(self, seq_group: SequenceGroup) -> None:
         self.block_manager.allocate(seq_group)

@@ -182,9 +182,12 @@ class LLMEngine:
         now = time.monotonic()        # intervals (TTFT, TPOT, e2e) are taken against the monotonic arrival_time
         wall = time.time()
         scheduled = list(scheduler_outputs.scheduled_seq_groups) if groups is None else groups
-        if self.cache_config.enable_prefix_caching:
+        if self.cache_config.enable_prefix_caching and (scheduler_outputs.prompt_run
+                                                        or not self.parallel_config.sep_prompt_token):
             # the step has written the KV of every full block of these sequences: later prompts with the
-            # same leading tokens need not compute them again (llm_engine.py:543-547)
+            # same leading tokens need not compute them again (llm_engine.py:543-547).  With split pools a
+            # decode step's KV exists on the token pool only: a prompt worker could not read it, so only
+            # prompt steps mark their blocks.
             for group in scheduled:
                 self.scheduler.mark_blocks_as_computed(group)
         for group, out in zip(scheduled, output):
@@ -254,7 +257,8 @@ class LLMEngine:
             self.scheduler.free_seq(seq)
         self._free_later = []
         reported: List[SequenceGroup] = []
-        if self.cache_config.enable_prefix_caching:
+        if self.cache_config.enable_prefix_caching and not self.parallel_config.sep_prompt_token:
+            # (split pools resolve only decode steps here, and those mark nothing: see _process_model_outputs)
             for group, seq in pairs:
                 if not seq.is_finished() or seq.has_placeholder():
                     self.scheduler.mark_blocks_as_computed(group)

@@ -101,12 +101,33 @@ class CustomAllreduce:
             raise RuntimeError("buffer address is not registered!")
         return self.all_reduce_unreg(inp, out, algorithm)
 
-    def check_status(self) -> None:
-        """Raises if a barrier ran out of its spin bound (host-synchronising)."""
+    def _status_word(self) -> torch.Tensor:
         off = self.signal_off + _C.custom_ar.signal_bytes() - 256
-        status = int(self.buffer[off:off + 4].view(torch.int32).item())
+        return self.buffer[off:off + 4].view(torch.int32)
+
+    def check_status(self) -> None:
+        """Raises if a barrier ran out of its spin bound (host-synchronising: off the hot path)."""
+        status = int(self._status_word().item())
         if status != 0:
             raise RuntimeError(f"all-reduce barrier timed out waiting for rank {status - 1}")
+
+    def check_status_after_step(self) -> None:
+        """The same check for the end of every step, without making the host wait for the device: the status
+        word travels to pinned host memory with a stream-ordered copy, and a call looks at what the copy
+        queued by an EARLIER call has brought (a timed-out barrier is reported one step late; a rank that
+        has run ahead of its device, as tensor-parallel followers do, keeps its lead)."""
+        if getattr(self, "_status_host", None) is None:
+            self._status_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+            self._status_event = None
+        if self._status_event is not None:
+            if not self._status_event.query():
+                return                               # the earlier copy is still queued behind device work
+            status = int(self._status_host[0])
+            if status != 0:
+                raise RuntimeError(f"all-reduce barrier timed out waiting for rank {status - 1}")
+        self._status_host.copy_(self._status_word(), non_blocking=True)
+        self._status_event = torch.cuda.Event()
+        self._status_event.record(torch.cuda.current_stream(self.device))
 
     def close(self) -> None:
         if getattr(self, "_ptr", 0):

@@ -75,6 +75,9 @@ class PendingSamples:
             for seq_id in seq_ids:
                 self.row_of[seq_id] = len(self.row_of)
         self.event = None
+        # events of other streams that the step's work is spread over (a prompt worker's KV pushes run on
+        # their own stream): the step has finished when these have completed too
+        self.extra_events = []
         self.after_sync = []         # callables run by resolve() once the step has finished on the device
         self._report_order = None    # see reorder()
         if next_ids.is_cuda:
@@ -91,15 +94,16 @@ class PendingSamples:
 
     def done(self) -> bool:
         """True once the step has finished on the device (resolve() will not block)."""
-        return self.event is None or self.event.query()
+        return (self.event is None or self.event.query()) and all(e.query() for e in self.extra_events)
 
     def wait(self) -> None:
         if self.event is not None:
             self.event.synchronize()
+        for event in self.extra_events:
+            event.synchronize()
 
     def resolve(self) -> SamplerOutput:
-        if self.event is not None:
-            self.event.synchronize()
+        self.wait()
         checks, self.after_sync = self.after_sync, []
         for check in checks:         # e.g. the worker's look at its hand-off / all-reduce status words
             check()

@@ -153,6 +153,17 @@ class KVCacheCommunicator:
         if self.push_stream is not None:
             self.push_stream.synchronize()
 
+    def pushes_done_event(self) -> Optional["torch.cuda.Event"]:
+        """An event behind everything queued on the push stream so far.  A prompt step has not finished
+        before it has completed: until then stores into the token worker's blocks are still in flight,
+        and a block that went back to the pool (a sequence that ended at its first token, an abort)
+        could be handed to a decoding sequence and then overwritten by the late push."""
+        if self.push_stream is None:
+            return None
+        event = torch.cuda.Event()
+        event.record(self.push_stream)
+        return event
+
     def put_many(self, layer_id: int, runs: Sequence[Tuple[int, int]]) -> None:
         """All (block_start, num_blocks) runs of one layer, K and V, in one launch."""
         if not runs:
@@ -312,3 +323,6 @@ class KVCacheCommManager:
 
     def put_many(self, layer_id: int, runs: Sequence[Tuple[int, int]]) -> None:
         self.kvcache_comm.put_many(layer_id, runs)
+
+    def pushes_done_event(self):
+        return self.kvcache_comm.pushes_done_event() if self.kvcache_comm is not None else None

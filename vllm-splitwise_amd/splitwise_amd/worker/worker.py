@@ -221,6 +221,14 @@ class Worker:
         if blocks_to_nw and comm is not None and self.is_prompt_worker() and is_prompt:
             for sem_id in blocks_to_nw:
                 comm.signal_and_flush(sem_id, nw_epochs.get(sem_id))
+            # the pushes and signals run on the transport's own stream: the step is over when they have left
+            # too (its blocks may be handed out again as soon as it is reported finished)
+            pushed = comm.pushes_done_event() if hasattr(comm, "pushes_done_event") else None
+            if pushed is not None:
+                if defer and hasattr(output, "extra_events"):
+                    output.extra_events.append(pushed)
+                else:
+                    pushed.synchronize()
         # a bounded wait that gave up (hand-off signal, all-reduce barrier) lets the stream run on over
         # data that never arrived: look at the status words once the step has finished and fail loudly
         # (the reference's proxy_channel.wait(1e8) traps, its all-reduce barrier hangs)
@@ -239,7 +247,7 @@ class Worker:
             from ..model_executor.custom_all_reduce import get_handle
             handle = get_handle()
             if handle is not None:
-                handle.check_status()
+                handle.check_status_after_step()
 
     def check_kv_status(self) -> None:
         """Host-synchronising form for callers outside a step (tests, the end of a benchmark)."""
