@@ -86,8 +86,9 @@ class Scheduler:
             num_cpu_blocks=cache_config.num_cpu_blocks, sliding_window=cache_config.sliding_window,
             enable_caching=cache_config.enable_prefix_caching)
         # split pools: only blocks written by a PROMPT step exist on both pools (the decode steps' KV lives on
-        # the token pool alone), so only those may be shared with later prompts
-        self.block_manager.promote_decode_blocks = not track_prompt_blocks
+        # the token pool alone), so only those may be shared with later prompts (the reference has no such
+        # guard: ``strict_reference`` keeps its behaviour)
+        self.block_manager.promote_decode_blocks = not track_prompt_blocks or strict_reference
         self.waiting: Deque[SequenceGroup] = deque()
         self.running: Deque[SequenceGroup] = deque()
         self.swapped: Deque[SequenceGroup] = deque()
