@@ -2,12 +2,18 @@
 """Headline benchmark: goodput (tok/s under a TTFT + TBT SLO) of Llama-2-7B serving.
 
   python bench.py [--gpus N] [--steps K] [--warmup W]
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (same result)
 
 N = 1  co-located serving on one MI355X (the configuration the metric is quoted on).
-N > 1  N/2 independent (prompt GPU, token GPU) pairs: every pair runs the split path with
-       the KV blocks of each prompt pushed prefill -> decode over xGMI; requests are
-       independent, so pairs share nothing (weak scaling, no data-path collective).
+N > 1  this process becomes a launcher that never touches a GPU and starts every engine as a fresh
+       child process (splitwise_amd/executor/bench_launch.py; under torchrun rank 0 is the launcher
+       and the other ranks leave at once).  Headline leg: N/2 independent (prompt GPU, token GPU)
+       pairs, every pair running the split path with the KV blocks of each prompt pushed prefill ->
+       decode over xGMI; requests are independent, so pairs share nothing (weak scaling, no data-path
+       collective).  Beside it, in the same JSON line under "legs": the same N GPUs as co-located
+       replicas ("vs_colocated"), one prompt GPU feeding two token GPUs, and the quantised /
+       tensor-parallel configurations that exist at this N (13B GPTQ + fp8 cache at N = 4, 70B
+       TP4 + TP4 pools at N = 8).  SPLITWISE_BENCH_ONE_GPU=1 rehearses any of it on a one-GPU box.
 
 A *step* is one engine iteration: one scheduling decision plus one pass of the hot path
 (a prompt batch or a decode batch) on the GPU.  The workload is closed-loop: C requests are
@@ -85,6 +91,15 @@ def parse_args():
                     help="print the generated tok/s of every run of this many timed steps (stderr)")
     ap.add_argument("--first-cohort", default="full", choices=["full", "random", "stratified"],
                     help="decode lengths of the first C requests: all L (default), random 1..L, or L*(i+1)/C shuffled")
+    # N > 1 only
+    ap.add_argument("--legs", default="default",
+                    help="N > 1: 'default' = every leg this N has, 'primary' = pairs + co-located only, or a "
+                         "comma-separated list of leg names")
+    ap.add_argument("--budget-s", type=float, default=840.0,
+                    help="N > 1: legs after the headline leg are skipped once the run has taken this long")
+    ap.add_argument("--leg-timeout", type=float, default=600.0, help="N > 1: longest any one leg may take (s)")
+    ap.add_argument("--replica", default=None, help=argparse.SUPPRESS)          # set by the launcher
+    ap.add_argument("--worker-cls", default=None, help=argparse.SUPPRESS)       # CPU dry runs of the launcher
     return ap.parse_args()
 
 
@@ -178,15 +193,7 @@ class ClosedLoop:
     def inflight_requests(self):
         """Request ids of the sequences in steps that the engine has launched and not collected yet (pipelined
         engines; empty otherwise).  Each of them gets one token from that step."""
-        eng = self.engine
-        ids = []
-        if getattr(eng, "_inflight", None) is not None:
-            ids += [group.request_id for group, _ in eng._inflight[2]]
-        if getattr(eng, "_decode_inflight", None) is not None:
-            ids += [group.request_id for group, _ in eng._decode_inflight[1]]
-        if getattr(eng, "_prompt_inflight", None) is not None:
-            ids += list(eng._prompt_inflight[2])
-        return ids
+        return self.engine.inflight_request_ids()
 
     def open_window(self):
         """Call at the start of the timed region, after the device synchronisation.  With pipelined steps the
@@ -348,12 +355,14 @@ def cpu_baseline(model_name, prompt_len, decode_len):
 
 def main():
     args = parse_args()
+    if args.replica is not None:                     # one replica of a multi-GPU leg, started by the launcher
+        from splitwise_amd.executor import bench_replica
+        return bench_replica.run(json.loads(args.replica))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 or world > 1:
-        from splitwise_amd.executor import bench_split
-        return bench_split.run(args, rank, local_rank, world)
+        args.gpus = max(args.gpus, world)
+        from splitwise_amd.executor import bench_launch
+        sys.exit(bench_launch.main(args))
 
     from splitwise_amd import EngineArgs, LLMEngine
     torch.cuda.set_device(0)

@@ -46,8 +46,11 @@ const char* sw_last_error(void);
 /* Version of this interface; sw_abi_version() returns the one the library was built from.
  * 2: sw_awq_to_kmajor, sw_int4_kmajor_gemm, sw_int4_kmajor_dequant added.
  * 3: sw_paged_attention_v2_static, sw_paged_attention_v2_static_max_bytes added.
- * 4: sw_kv_push takes max_workgroups. */
-#define SW_ABI_VERSION 5
+ * 4: sw_kv_push takes max_workgroups.
+ * 5: sw_rotary_embedding_and_cache added; the all-reduce signal area (sw_custom_ar_signal_bytes)
+ *    grew from 2304 to 2560 bytes, which moves the status word at its end.
+ * 6: sw_kv_push_mapped added. */
+#define SW_ABI_VERSION 6
 int sw_abi_version(void);
 
 /* csrc/cuda_utils_kernels.cu:16-35 get_max_shared_memory_per_block_device_attribute:
@@ -198,6 +201,14 @@ int sw_ipc_close_mem_handle(void* dev_ptr);
  * the kernels it runs beside; <= 0 launches one workgroup per chunk (device-local copies).     */
 int sw_kv_push(void* dst_base, const void* src_base, const int64_t* offsets,
                const int64_t* nbytes, int num_runs, int max_workgroups, void* stream);
+
+/* sw_kv_push with a destination offset of its own for every range: src_base + src_offsets[i] ->
+ * dst_base + dst_offsets[i].  The reference registers the two caches under the same block numbers
+ * (comm_utils.py:132-147 uses one offset for both sides); a prompt worker that keeps only the blocks
+ * of the prompts in flight, or that feeds several token workers, numbers its blocks by itself.     */
+int sw_kv_push_mapped(void* dst_base, const void* src_base, const int64_t* dst_offsets,
+                      const int64_t* src_offsets, const int64_t* nbytes, int num_runs,
+                      int max_workgroups, void* stream);
 
 /* nw_cache_out_signal_kernel (kv_comm_kernels.cu:22-29): after a system-scope release,
  * flags[slot] := epoch in the PEER's flag array (IPC mapping).  Ordered after every earlier

@@ -32,6 +32,9 @@ class PipelinedEngine:
     def add_request(self, request_id, prompt, params, prompt_token_ids=None):
         self.groups[request_id] = _Group(request_id, params.max_tokens)
 
+    def inflight_request_ids(self):
+        return [g.request_id for g, _ in self._inflight[2]] if self._inflight is not None else []
+
     def step(self):
         previous = self._inflight
         live = [g for g in self.groups.values() if g.launched < g.max_tokens]

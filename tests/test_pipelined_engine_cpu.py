@@ -178,9 +178,11 @@ class FakeSplitExecutor(ExecutorBase):
         self.prompt_pending = _PromptPending(kwargs["seq_group_metadata_list"])
         return self.prompt_pending
 
-    def decode_deferred(self, kwargs):
-        prev, self.decode_prev = self.decode_prev, (kwargs["seq_group_metadata_list"] if kwargs else None)
-        return _sample(prev) if prev is not None else None
+    def decode_send(self, kwargs):
+        self.decode_before, self.decode_prev = self.decode_prev, (kwargs["seq_group_metadata_list"] if kwargs else None)
+
+    def decode_collect(self):
+        return _sample(self.decode_before) if self.decode_before is not None else None
 
     def check_health(self) -> None:
         pass

@@ -6,6 +6,8 @@
 // worker's cache is mapped into the prompt worker's address space (HIP IPC over xGMI) and
 //   * sw_kv_push   copies byte ranges local cache -> peer cache, same offset on both sides
 //                  (comm_utils.py:132-147), 16 bytes per lane, any number of ranges per launch;
+//   * sw_kv_push_mapped  the same with a destination offset of its own per range: a prompt worker that
+//                  keeps only the prompts in flight, under block numbers of its own;
 //   * sw_kv_signal publishes a per-sequence hand-off flag in the peer's memory after a
 //                  system-scope release (ordered after every earlier push on the stream);
 //   * sw_kv_wait   spins (bounded, like the reference's 1e8 bound) on the local flag with
@@ -24,7 +26,8 @@ constexpr int kPushThreads = 256;
 constexpr int64_t kChunkBytes = 64 * 1024;          // bytes one workgroup moves
 
 struct PushRuns {
-  int64_t offset[kMaxRuns];     // byte offset from both bases, multiple of 16
+  int64_t offset[kMaxRuns];     // byte offset from the destination base, multiple of 16
+  int64_t src_offset[kMaxRuns]; // byte offset from the source base, multiple of 16
   int64_t nbytes[kMaxRuns];     // multiple of 16
   int32_t first_chunk[kMaxRuns + 1];
   int32_t num_runs;
@@ -46,7 +49,7 @@ kv_push_kernel(char* __restrict__ dst_base, const char* __restrict__ src_base, P
   const int64_t begin = (int64_t)(chunk - runs.first_chunk[r]) * kChunkBytes;
   const int64_t end = min(begin + kChunkBytes, runs.nbytes[r]);
   const int nbytes = (int)(end - begin);
-  const uint4* src = reinterpret_cast<const uint4*>(src_base + runs.offset[r] + begin);
+  const uint4* src = reinterpret_cast<const uint4*>(src_base + runs.src_offset[r] + begin);
   // wave-uniform destination descriptor for this chunk (bounds-checked by the hardware)
   uint64_t d = reinterpret_cast<uint64_t>(dst_base + runs.offset[r] + begin);
   const uint32_t d_lo = __builtin_amdgcn_readfirstlane((uint32_t)d);
@@ -135,11 +138,12 @@ int sw_ipc_close_mem_handle(void* dev_ptr) {
   return SW_OK;
 }
 
-int sw_kv_push(void* dst_base, const void* src_base, const int64_t* offsets, const int64_t* nbytes,
-               int num_runs, int max_workgroups, void* stream) {
+int sw_kv_push_mapped(void* dst_base, const void* src_base, const int64_t* dst_offsets,
+                      const int64_t* src_offsets, const int64_t* nbytes, int num_runs, int max_workgroups,
+                      void* stream) {
   using namespace sw;
   if (num_runs == 0) return SW_OK;
-  SW_CHECK_ARG(dst_base && src_base && offsets && nbytes && num_runs > 0, "kv_push: bad arguments");
+  SW_CHECK_ARG(dst_base && src_base && dst_offsets && src_offsets && nbytes && num_runs > 0, "kv_push: bad arguments");
   SW_CHECK_ARG(reinterpret_cast<uintptr_t>(dst_base) % 16 == 0 && reinterpret_cast<uintptr_t>(src_base) % 16 == 0,
                "kv_push: bases must be 16-byte aligned");
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -148,11 +152,12 @@ int sw_kv_push(void* dst_base, const void* src_base, const int64_t* offsets, con
     PushRuns runs;
     int chunks = 0, n = 0;
     for (; n < kMaxRuns && done + n < num_runs; ++n) {
-      const int64_t off = offsets[done + n], nb = nbytes[done + n];
-      SW_CHECK_ARG(off >= 0 && nb > 0 && off % 16 == 0 && nb % 16 == 0,
-                   "kv_push: run %d (offset %lld, %lld bytes) is not 16-byte granular", done + n,
-                   (long long)off, (long long)nb);
+      const int64_t off = dst_offsets[done + n], soff = src_offsets[done + n], nb = nbytes[done + n];
+      SW_CHECK_ARG(off >= 0 && soff >= 0 && nb > 0 && off % 16 == 0 && soff % 16 == 0 && nb % 16 == 0,
+                   "kv_push: run %d (offsets %lld <- %lld, %lld bytes) is not 16-byte granular", done + n,
+                   (long long)off, (long long)soff, (long long)nb);
       runs.offset[n] = off;
+      runs.src_offset[n] = soff;
       runs.nbytes[n] = nb;
       runs.first_chunk[n] = chunks;
       const int64_t c = (nb + kChunkBytes - 1) / kChunkBytes;
@@ -168,6 +173,11 @@ int sw_kv_push(void* dst_base, const void* src_base, const int64_t* offsets, con
     done += n;
   }
   return SW_OK;
+}
+
+int sw_kv_push(void* dst_base, const void* src_base, const int64_t* offsets, const int64_t* nbytes,
+               int num_runs, int max_workgroups, void* stream) {
+  return sw_kv_push_mapped(dst_base, src_base, offsets, offsets, nbytes, num_runs, max_workgroups, stream);
 }
 
 int sw_kv_signal(int32_t* flags, int slot, int32_t epoch, void* stream) {

@@ -66,6 +66,7 @@ _SIGNATURES = {
     "sw_ipc_open_mem_handle": [_c_void_p, ctypes.POINTER(_c_void_p)],
     "sw_ipc_close_mem_handle": [_c_void_p],
     "sw_kv_push": [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_void_p],
+    "sw_kv_push_mapped": [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_void_p],
     "sw_kv_signal": [_c_void_p, _c_int, ctypes.c_int32, _c_void_p],
     "sw_kv_wait": [_c_void_p, _c_int, ctypes.c_int32, _c_i64, _c_void_p, _c_void_p],
     "sw_context_attention": [_c_void_p] * 7 + [_c_int] + [_c_void_p] * 3 + [_c_int] * 6 + [ctypes.c_float, _c_void_p]
@@ -99,7 +100,7 @@ def library_path() -> str:
     return _LIB_PATH
 
 
-ABI_VERSION = 5                # SW_ABI_VERSION of include/splitwise_hip.h this binding was written against
+ABI_VERSION = 6                # SW_ABI_VERSION of include/splitwise_hip.h this binding was written against
 
 
 def load_library() -> ctypes.CDLL:
@@ -561,6 +562,21 @@ def kv_push(dst_base: int, src_base: int, offsets: List[int], nbytes: List[int],
                                      int(max_workgroups), stream))
 
 
+def kv_push_mapped(dst_base: int, src_base: int, dst_offsets: List[int], src_offsets: List[int], nbytes: List[int],
+                   stream: int, max_workgroups: int = 0) -> None:
+    """kv_push with a destination offset of its own per range."""
+    n = len(dst_offsets)
+    if n == 0:
+        return
+    if len(src_offsets) != n or len(nbytes) != n:
+        raise RuntimeError("kv_push_mapped: offset and size lists differ in length")
+    dst = (ctypes.c_int64 * n)(*dst_offsets)
+    src = (ctypes.c_int64 * n)(*src_offsets)
+    nb = (ctypes.c_int64 * n)(*nbytes)
+    _check(load_library().sw_kv_push_mapped(dst_base, src_base, ctypes.addressof(dst), ctypes.addressof(src),
+                                            ctypes.addressof(nb), n, int(max_workgroups), stream))
+
+
 def kv_signal(flags_ptr: int, slot: int, epoch: int, stream: int) -> None:
     _check(load_library().sw_kv_signal(flags_ptr, slot, epoch, stream))
 
@@ -792,6 +808,7 @@ kv_ops = SimpleNamespace(
     ipc_open_mem_handle=ipc_open_mem_handle,
     ipc_close_mem_handle=ipc_close_mem_handle,
     kv_push=kv_push,
+    kv_push_mapped=kv_push_mapped,
     kv_signal=kv_signal,
     kv_wait=kv_wait,
 )

@@ -157,9 +157,19 @@ class ParallelConfig:
     a token pool of tensor_parallel_size ranks each (:433-443)."""
 
     def __init__(self, pipeline_parallel_size: int = 1, tensor_parallel_size: int = 1,
-                 sep_prompt_token: bool = False, disable_custom_all_reduce: bool = False) -> None:
+                 sep_prompt_token: bool = False, disable_custom_all_reduce: bool = False,
+                 token_pools: int = 1, staged_prompt_cache: bool = False) -> None:
+        """``token_pools`` (with sep_prompt_token): token pools fed by the one prompt pool.  The reference
+        has exactly one (:434-438: as many token workers as prompt workers); with more, pool j is ranks
+        tp * (1 + j) .. tp * (2 + j) - 1 and prompt rank r pushes a sequence's KV to rank r of the pool the
+        sequence decodes on.  ``staged_prompt_cache``: the prompt pool keeps only the blocks of the prompts
+        in flight, under block numbers of its own (implied by more than one token pool: their caches are
+        separate block spaces); without it a block number names the same block on both pools, as in the
+        reference (vllm/worker/comm_utils.py:132-147)."""
         if pipeline_parallel_size > 1:
             raise NotImplementedError("Pipeline parallelism is not supported yet.")
+        if token_pools < 1 or (token_pools > 1 and not sep_prompt_token):
+            raise ValueError("token_pools > 1 needs sep_prompt_token")
         self.pipeline_parallel_size = pipeline_parallel_size
         self.tensor_parallel_size = tensor_parallel_size
         self.sep_prompt_token = sep_prompt_token
@@ -167,9 +177,11 @@ class ParallelConfig:
         self.world_size = pipeline_parallel_size * tensor_parallel_size
         self.num_prompt_workers = 0
         self.num_token_workers = 0
+        self.num_token_pools = token_pools if sep_prompt_token else 0
+        self.staged_prompt_cache = sep_prompt_token and (staged_prompt_cache or token_pools > 1)
         if sep_prompt_token:
             self.num_prompt_workers = self.world_size
-            self.num_token_workers = self.world_size
+            self.num_token_workers = self.world_size * token_pools
             self.world_size = self.num_prompt_workers + self.num_token_workers
 
 

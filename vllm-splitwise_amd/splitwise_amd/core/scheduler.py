@@ -410,3 +410,69 @@ class Scheduler:
         blocks_to_swap_in.update(self.block_manager.swap_in(seq_group))
         for seq in seq_group.get_seqs(status=SequenceStatus.SWAPPED):
             seq.status = SequenceStatus.RUNNING
+
+
+class _PooledBlockCounts:
+    """Free-block totals over several block managers (statistics only)."""
+
+    def __init__(self, managers: List[BlockSpaceManager]) -> None:
+        self.managers = managers
+
+    def get_num_free_gpu_blocks(self) -> int:
+        return sum(m.get_num_free_gpu_blocks() for m in self.managers)
+
+    def get_num_free_cpu_blocks(self) -> int:
+        return sum(m.get_num_free_cpu_blocks() for m in self.managers)
+
+
+class SchedulerGroup:
+    """The schedulers of several token pools behind the queue-administration interface of one.
+
+    Each token pool is a block space and a set of hand-off slots of its own, so each has its own
+    ``Scheduler``; a request is bound to a pool when it arrives -- the one with the fewest unfinished
+    requests -- and stays there (its KV lives in that pool's cache).  The reference's world has a single
+    token pool (vllm/config.py:434-438) and needs none of this.  Scheduling itself is asked of the
+    member schedulers directly (``LLMEngine.schedulers``)."""
+
+    def __init__(self, lanes: List[Scheduler]) -> None:
+        self.lanes = lanes
+        self.block_manager = _PooledBlockCounts([s.block_manager for s in lanes])
+
+    def add_seq_group(self, seq_group: SequenceGroup) -> None:
+        lane = min(range(len(self.lanes)), key=lambda i: self.lanes[i].get_num_unfinished_seq_groups())
+        self.lanes[lane].add_seq_group(seq_group)
+
+    def abort_seq_group(self, request_id: Union[str, Iterable[str]]) -> None:
+        ids = [request_id] if isinstance(request_id, str) else list(request_id)
+        for lane in self.lanes:
+            lane.abort_seq_group(ids)
+
+    def release_held(self) -> None:
+        for lane in self.lanes:
+            lane.release_held()
+
+    def has_unfinished_seqs(self) -> bool:
+        return any(lane.has_unfinished_seqs() for lane in self.lanes)
+
+    def get_num_unfinished_seq_groups(self) -> int:
+        return sum(lane.get_num_unfinished_seq_groups() for lane in self.lanes)
+
+    @property
+    def waiting(self) -> List[SequenceGroup]:
+        return [g for lane in self.lanes for g in lane.waiting]
+
+    @property
+    def running(self) -> List[SequenceGroup]:
+        return [g for lane in self.lanes for g in lane.running]
+
+    @property
+    def swapped(self) -> List[SequenceGroup]:
+        return [g for lane in self.lanes for g in lane.swapped]
+
+    @property
+    def held_after_abort(self) -> List[Sequence]:
+        return [s for lane in self.lanes for s in lane.held_after_abort]
+
+    @property
+    def num_preemptions(self) -> int:
+        return sum(getattr(lane, "num_preemptions", 0) for lane in self.lanes)

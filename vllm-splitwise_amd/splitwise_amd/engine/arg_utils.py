@@ -19,6 +19,8 @@ class EngineArgs:
     pipeline_parallel_size: int = 1
     tensor_parallel_size: int = 1
     sep_prompt_token: bool = False
+    token_pools: int = 1             # token pools fed by the prompt pool (the reference has one)
+    staged_prompt_cache: bool = False  # prompt pool keeps only the prompts in flight, under its own block numbers
     disable_custom_all_reduce: bool = False
     block_size: int = 16
     enable_prefix_caching: bool = False
@@ -60,7 +62,11 @@ class EngineArgs:
                                    self.kv_cache_dtype, model_config.get_sliding_window(),
                                    self.enable_prefix_caching)
         parallel_config = ParallelConfig(self.pipeline_parallel_size, self.tensor_parallel_size,
-                                         self.sep_prompt_token, self.disable_custom_all_reduce)
+                                         self.sep_prompt_token, self.disable_custom_all_reduce,
+                                         self.token_pools, self.staged_prompt_cache)
+        if parallel_config.staged_prompt_cache and self.enable_prefix_caching:
+            raise NotImplementedError("prefix caching needs the prompt pool to keep its blocks: it cannot be "
+                                      "combined with staged_prompt_cache / token_pools > 1")
         model_config.verify_with_parallel_config(parallel_config)
         scheduler_config = SchedulerConfig(self.max_num_batched_tokens, self.max_num_seqs,
                                            model_config.max_model_len, self.max_paddings,

@@ -10,11 +10,12 @@ import time
 from typing import Dict, Iterable, List, Optional, Union
 
 from ..config import CacheConfig, DeviceConfig, ModelConfig, ParallelConfig, SchedulerConfig
-from ..core.scheduler import Scheduler, SchedulerOutputs
+from ..core.scheduler import Scheduler, SchedulerGroup, SchedulerOutputs
 from ..outputs import RequestOutput
 from ..sampling_params import SamplingParams
 from ..sequence import (SamplerOutput, Sequence, SequenceGroup, SequenceGroupMetadata, SequenceStatus)
 from ..transformers_utils.tokenizer import detokenize_incrementally, get_tokenizer
+from ..utils import coalesce_block_pairs
 from .arg_utils import EngineArgs
 from .metrics import StatLogger, Stats
 
@@ -50,15 +51,24 @@ class LLMEngine:
                     executor_class = GPUExecutor
             self.model_executor = executor_class(model_config, cache_config, parallel_config, scheduler_config,
                                                  device_config, num_gpu_blocks_override=num_gpu_blocks_override)
-        self.scheduler = Scheduler(scheduler_config, cache_config, None,
-                                   track_prompt_blocks=parallel_config.sep_prompt_token)
+        # one scheduler -- one block space, one set of hand-off slots -- per token pool ("lane"); the
+        # reference's world has one (vllm/config.py:434-438)
+        lanes = max(getattr(parallel_config, "num_token_pools", 1), 1)
+        self.schedulers = [Scheduler(scheduler_config, cache_config, None,
+                                     track_prompt_blocks=parallel_config.sep_prompt_token) for _ in range(lanes)]
+        self.scheduler = self.schedulers[0] if lanes == 1 else SchedulerGroup(self.schedulers)
+        # a prompt pool that keeps only the prompts in flight hands out its own block numbers, step by step
+        self.staged_prompt_cache = bool(getattr(parallel_config, "staged_prompt_cache", False))
+        self._staging_blocks = getattr(self.model_executor, "prompt_cache_blocks", None)
+        if self.staged_prompt_cache and not self._staging_blocks:
+            raise ValueError("staged_prompt_cache needs an executor that sizes the prompt pool's cache by itself")
         self.stat_logger = None
         if log_stats:
             self.stat_logger = StatLogger(local_interval=5.0, labels=dict(model_name=model_config.model))
             self.stat_logger.info("cache_config", cache_config)
         # split pools: run a prompt step and a decode step concurrently when the executor can
         self.overlap_pools = parallel_config.sep_prompt_token and hasattr(self.model_executor, "execute_split")
-        self._slot_epoch: Dict[int, int] = {}
+        self._slot_epoch: Dict[tuple, int] = {}        # (lane, hand-off slot) -> hand-offs so far
         # pipelined steps (co-located engine only): step n+1 is scheduled and launched while step n
         # still runs; a step's tokens are appended, and its outputs returned, one call later
         self.pipeline_steps = (getattr(scheduler_config, "pipeline_steps", False) and not self.overlap_pools
@@ -67,11 +77,16 @@ class LLMEngine:
         # split pools, pipelined: the prompt pool and the token pool each have a step in flight
         self.pipeline_split = (getattr(scheduler_config, "pipeline_steps", False) and self.overlap_pools
                                and getattr(self.model_executor, "supports_pipelined_split", False))
-        self._prompt_inflight = None    # (pending samples, scheduler outputs, request ids)
-        self._decode_inflight = None    # (scheduler outputs, [(group, sequence)])
-        self._free_later: List[Sequence] = []
+        self._prompt_inflight = None    # (pending samples, scheduler outputs, request ids, lane)
+        self._decode_inflight: List[Optional[tuple]] = [None] * lanes   # per lane: (scheduler outputs, [(group, sequence)])
+        self._free_later: List[List[Sequence]] = [[] for _ in range(lanes)]
+        self._next_prompt_lane = 0
+        if (lanes > 1 or self.staged_prompt_cache) and not self.pipeline_split:
+            raise NotImplementedError("several token pools / a staged prompt cache need pipeline_steps and an "
+                                      "executor with launch_prompt / decode_send / decode_collect")
         if self.pipeline_split:
-            self.scheduler.in_flight = self._seq_in_flight
+            for sched in self.schedulers:
+                sched.in_flight = self._seq_in_flight
         # Everything built so far (modules, parameters, captured graphs, block tables) lives as long as the engine
         # does.  Python's cyclic collector would walk all of it on every full collection -- tens of milliseconds
         # in the middle of a serving loop, 4 % of the closed-loop benchmark's throughput -- so those objects are
@@ -87,10 +102,23 @@ class LLMEngine:
             for group in self._prompt_inflight[1].scheduled_seq_groups:
                 if any(s.seq_id == seq.seq_id for s in group.get_seqs()):
                     return True
-        if self._decode_inflight is not None:
-            if any(s.seq_id == seq.seq_id for _, s in self._decode_inflight[1]):
+        for inflight in self._decode_inflight:
+            if inflight is not None and any(s.seq_id == seq.seq_id for _, s in inflight[1]):
                 return True
         return False
+
+    def inflight_request_ids(self) -> List[str]:
+        """Request ids of the sequences in steps that have been launched and not collected yet (pipelined
+        steps; empty otherwise).  Each of them gets one token from that step."""
+        ids: List[str] = []
+        if self._inflight is not None:
+            ids += [group.request_id for group, _ in self._inflight[2]]
+        for inflight in self._decode_inflight:
+            if inflight is not None:
+                ids += [group.request_id for group, _ in inflight[1]]
+        if self._prompt_inflight is not None:
+            ids += list(self._prompt_inflight[2])
+        return ids
 
     @classmethod
     def from_engine_args(cls, engine_args: EngineArgs, **kwargs) -> "LLMEngine":
@@ -123,8 +151,8 @@ class LLMEngine:
 
     def has_unfinished_requests(self) -> bool:
         return (self.scheduler.has_unfinished_seqs() or self._inflight is not None
-                or self._prompt_inflight is not None or self._decode_inflight is not None or bool(self._free_later)
-                or bool(self.scheduler.held_after_abort))
+                or self._prompt_inflight is not None or any(d is not None for d in self._decode_inflight)
+                or any(self._free_later) or bool(self.scheduler.held_after_abort))
 
     # --------------------------------------------------------------------- step
     def _decode_sequence(self, seq: Sequence, params: SamplingParams) -> None:
@@ -178,9 +206,10 @@ class LLMEngine:
             seq.status = SequenceStatus.FINISHED_STOPPED
 
     def _process_model_outputs(self, output: SamplerOutput, scheduler_outputs: SchedulerOutputs,
-                               groups: Optional[List[SequenceGroup]] = None) -> List[RequestOutput]:
+                               groups: Optional[List[SequenceGroup]] = None, lane: int = 0) -> List[RequestOutput]:
         now = time.monotonic()        # intervals (TTFT, TPOT, e2e) are taken against the monotonic arrival_time
         wall = time.time()
+        scheduler = self.schedulers[lane]
         scheduled = list(scheduler_outputs.scheduled_seq_groups) if groups is None else groups
         if self.cache_config.enable_prefix_caching and (scheduler_outputs.prompt_run
                                                         or not self.parallel_config.sep_prompt_token):
@@ -189,7 +218,7 @@ class LLMEngine:
             # decode step's KV exists on the token pool only: a prompt worker could not read it, so only
             # prompt steps mark their blocks.
             for group in scheduled:
-                self.scheduler.mark_blocks_as_computed(group)
+                scheduler.mark_blocks_as_computed(group)
         for group, out in zip(scheduled, output):
             seq = group.get_seqs(status=SequenceStatus.RUNNING)[0]
             sample = out.samples[0]
@@ -197,9 +226,9 @@ class LLMEngine:
             self._decode_sequence(seq, group.sampling_params)
             self._check_stop(seq, group.sampling_params)
             if seq.is_finished():
-                self.scheduler.free_seq(seq)
+                scheduler.free_seq(seq)
             group.maybe_set_first_token_time(wall)
-        self.scheduler.free_finished_seq_groups()
+        scheduler.free_finished_seq_groups()
         request_outputs = [RequestOutput.from_seq_group(g) for g in scheduled]
         request_outputs += [RequestOutput.from_seq_group(g) for g in scheduler_outputs.ignored_seq_groups]
         if self.stat_logger is not None:
@@ -215,15 +244,15 @@ class LLMEngine:
         prompt_kwargs = decode_kwargs = None
         if metas_p:
             for slot in outs_p.blocks_to_nw:
-                self._slot_epoch[slot] = self._slot_epoch.get(slot, 0) + 1
+                self._slot_epoch[(0, slot)] = self._slot_epoch.get((0, slot), 0) + 1
             prompt_kwargs = dict(seq_group_metadata_list=metas_p, blocks_to_swap_in={}, blocks_to_swap_out={},
                                  blocks_to_copy={}, blocks_to_nw=outs_p.blocks_to_nw,
-                                 nw_epochs={s: self._slot_epoch[s] for s in outs_p.blocks_to_nw})
+                                 nw_epochs={s: self._slot_epoch[(0, s)] for s in outs_p.blocks_to_nw})
         if not outs_d.is_empty():
             decode_kwargs = dict(seq_group_metadata_list=metas_d, blocks_to_swap_in=outs_d.blocks_to_swap_in,
                                  blocks_to_swap_out=outs_d.blocks_to_swap_out, blocks_to_copy=outs_d.blocks_to_copy,
                                  blocks_to_nw=outs_d.blocks_to_nw,
-                                 nw_epochs={s: self._slot_epoch.get(s, 0) for s in outs_d.blocks_to_nw})
+                                 nw_epochs={s: self._slot_epoch.get((0, s), 0) for s in outs_d.blocks_to_nw})
         prompt_out, decode_out = self.model_executor.execute_split(prompt_kwargs, decode_kwargs)
         outputs: List[RequestOutput] = []
         if decode_out is not None and metas_d:
@@ -246,22 +275,23 @@ class LLMEngine:
         return self._apply_deferred(pending.resolve(), scheduler_outputs, pairs)
 
     def _apply_deferred(self, output: SamplerOutput, scheduler_outputs: SchedulerOutputs, pairs,
-                        still_running=()) -> List[RequestOutput]:
+                        still_running=(), lane: int = 0) -> List[RequestOutput]:
         """Fills in the tokens of a step whose sequences have carried placeholders since its launch.
         ``still_running``: ids of the sequences in a newer step that is already in flight (split
         pools only): their blocks must outlive that step, because the prompt GPU does not queue
         behind the token GPU's stream when it writes new KV into reused blocks."""
         now = time.monotonic()        # intervals (TTFT, TPOT, e2e) are taken against the monotonic arrival_time
         wall = time.time()
-        for seq in self._free_later:                     # their speculative extra step has resolved by now
-            self.scheduler.free_seq(seq)
-        self._free_later = []
+        scheduler = self.schedulers[lane]
+        for seq in self._free_later[lane]:               # their speculative extra step has resolved by now
+            scheduler.free_seq(seq)
+        self._free_later[lane] = []
         reported: List[SequenceGroup] = []
         if self.cache_config.enable_prefix_caching and not self.parallel_config.sep_prompt_token:
             # (split pools resolve only decode steps here, and those mark nothing: see _process_model_outputs)
             for group, seq in pairs:
                 if not seq.is_finished() or seq.has_placeholder():
-                    self.scheduler.mark_blocks_as_computed(group)
+                    scheduler.mark_blocks_as_computed(group)
         for (group, seq), out in zip(pairs, output):
             if not seq.has_placeholder():
                 continue        # ended (stop token, abort) before this step's token was accounted for: dropped
@@ -276,26 +306,27 @@ class LLMEngine:
                 if (self._stop_string_hit(seq, group.sampling_params)
                         or sample.output_token in group.sampling_params.stop_token_ids):
                     seq.status = SequenceStatus.FINISHED_STOPPED
-                self.scheduler.free_seq(seq)            # no-op when the blocks went back at launch
+                scheduler.free_seq(seq)            # no-op when the blocks went back at launch
             else:
                 self._check_stop(seq, group.sampling_params)
                 if seq.is_finished():
                     if seq.seq_id in still_running:
-                        self._free_later.append(seq)
+                        self._free_later[lane].append(seq)
                     else:
-                        self.scheduler.free_seq(seq)
-                    if group in self.scheduler.waiting:      # preempted for recomputation in the meantime
-                        self.scheduler.waiting.remove(group)
+                        scheduler.free_seq(seq)
+                    if group in scheduler.waiting:      # preempted for recomputation in the meantime
+                        scheduler.waiting.remove(group)
             group.maybe_set_first_token_time(wall)
             reported.append(group)
-        self.scheduler.free_finished_seq_groups()
+        scheduler.free_finished_seq_groups()
         if self.stat_logger is not None:
             self.stat_logger.log(self._get_stats(scheduler_outputs, reported, now))
         return [RequestOutput.from_seq_group(g) for g in reported]
 
-    def _launch_bookkeeping(self, pairs) -> None:
+    def _launch_bookkeeping(self, pairs, lane: int = 0) -> None:
         """After a deferred step has been launched and the previous one resolved: every sequence of
         the new step gets its placeholder; the ones that end by length are retired at once."""
+        scheduler = self.schedulers[lane]
         for group, seq in pairs:
             if seq.is_finished():
                 continue            # a stop token of the previous step ended it; this step's sample is dropped
@@ -306,59 +337,115 @@ class LLMEngine:
                 # once.  Split pools: the prompt GPU writes new KV into the token GPU's blocks on its own
                 # clock, so these blocks stay taken until the step that still reads them has resolved.
                 if not self.pipeline_split:
-                    self.scheduler.free_seq(seq)
-        self.scheduler.free_finished_seq_groups()
+                    scheduler.free_seq(seq)
+        scheduler.free_finished_seq_groups()
+
+    def _stage_prompt_step(self, lane: int, metas_p: List[SequenceGroupMetadata], outs_p: SchedulerOutputs):
+        """The prompt pool keeps only the prompts in flight, under block numbers of its own: every prompt of
+        the step gets consecutive blocks 0, 1, 2, ... of the half of the prompt cache that the previous step
+        does not occupy, the commands carry those numbers, and the hand-off runs say where each of them goes
+        in the token pool's cache.  -> (commands for the prompt pool, {slot: [(src, dst, length), ...]})"""
+        half = self._staging_blocks // 2
+        base = half * (self._staging_parity & 1)
+        self._staging_parity += 1
+        scheduler = self.schedulers[lane]
+        staged: List[SequenceGroupMetadata] = []
+        runs: Dict[int, List[tuple]] = {}
+        cursor = 0
+        for meta in metas_p:
+            tables = {}
+            for seq_id, table in meta.block_tables.items():
+                if len(set(table)) != len(table):
+                    raise NotImplementedError("a staged prompt cache cannot hold a sliding window's repeated blocks")
+                mine = list(range(base + cursor, base + cursor + len(table)))
+                cursor += len(table)
+                tables[seq_id] = mine
+                slot = scheduler.seq_to_slot_mapper.get_slot_id(seq_id)
+                if slot in outs_p.blocks_to_nw:                  # due for a hand-off (every admitted prompt is)
+                    runs.setdefault(slot, []).extend(coalesce_block_pairs(mine, table))
+            staged.append(SequenceGroupMetadata(request_id=meta.request_id, is_prompt=True, seq_data=meta.seq_data,
+                                                sampling_params=meta.sampling_params, block_tables=tables,
+                                                computed_block_nums=[], state=meta.state))
+        if cursor > half:
+            raise RuntimeError(f"a prompt step of {cursor} blocks does not fit the prompt pool's {half}-block stage")
+        return staged, runs
+
+    _staging_parity = 0
 
     def _step_split_pipelined(self) -> List[RequestOutput]:
-        """Prompt pool and token pool run free of each other: a prompt step is started whenever the
+        """Prompt pool and token pool(s) run free of each other: a prompt step is started whenever the
         prompt pool is idle and collected when it has finished; every call starts the next decode
-        step and collects the previous one, so the token GPU always has a step queued."""
+        step of every token pool and collects the previous one, so a token GPU always has a step queued.
+        With several token pools a prompt step serves the waiting prompts of ONE pool (each pool has its own
+        block space and hand-off slots); the pools take turns."""
         ex = self.model_executor
+        lanes = len(self.schedulers)
         outputs: List[RequestOutput] = []
         progressed = False
         # ---- prompt pool
         if self._prompt_inflight is not None and self._prompt_inflight[0].done():
-            pending, outs_p, ids = self._prompt_inflight
+            pending, outs_p, ids, lane = self._prompt_inflight
             self._prompt_inflight = None
             sampled = pending.resolve()
             live = [(g, o) for g, o in zip(outs_p.scheduled_seq_groups, sampled)
                     if g.get_seqs(status=SequenceStatus.RUNNING)]              # not aborted meanwhile
             outputs += self._process_model_outputs(SamplerOutput([o for _, o in live]), outs_p,
-                                                   groups=[g for g, _ in live])
-            self.scheduler.prompt_step_done(ids)
+                                                   groups=[g for g, _ in live], lane=lane)
+            self.schedulers[lane].prompt_step_done(ids)
             progressed = True
         if self._prompt_inflight is None:
-            metas_p, outs_p = self.scheduler.schedule_prompts()
-            if metas_p:
-                for slot in outs_p.blocks_to_nw:
-                    self._slot_epoch[slot] = self._slot_epoch.get(slot, 0) + 1
-                pending = ex.launch_prompt(dict(
-                    seq_group_metadata_list=metas_p, blocks_to_swap_in={}, blocks_to_swap_out={}, blocks_to_copy={},
-                    blocks_to_nw=outs_p.blocks_to_nw, nw_epochs={s: self._slot_epoch[s] for s in outs_p.blocks_to_nw}))
-                outs_p.scheduled_seq_groups = list(outs_p.scheduled_seq_groups)
-                self._prompt_inflight = (pending, outs_p, [m.request_id for m in metas_p])
-                progressed = True
-            else:                                              # (with a launch they are reported when it resolves)
+            for turn in range(lanes):
+                lane = (self._next_prompt_lane + turn) % lanes
+                metas_p, outs_p = self.schedulers[lane].schedule_prompts()
+                if metas_p:
+                    break
                 outputs += [RequestOutput.from_seq_group(g) for g in outs_p.ignored_seq_groups]
-        # ---- token pool
-        metas_d, outs_d = self.scheduler.schedule_decodes()
-        decode_kwargs, pairs = None, None
-        if metas_d:
-            pairs = [(g, g.get_seqs(status=SequenceStatus.RUNNING)[0]) for g in outs_d.scheduled_seq_groups]
-            decode_kwargs = dict(seq_group_metadata_list=metas_d, blocks_to_swap_in=outs_d.blocks_to_swap_in,
-                                 blocks_to_swap_out=outs_d.blocks_to_swap_out, blocks_to_copy=outs_d.blocks_to_copy,
-                                 blocks_to_nw=outs_d.blocks_to_nw,
-                                 nw_epochs={s: self._slot_epoch.get(s, 0) for s in outs_d.blocks_to_nw})
-        if decode_kwargs is not None or self._decode_inflight is not None:
-            previous = ex.decode_deferred(decode_kwargs)
-            if self._decode_inflight is not None:
-                outs_prev, pairs_prev = self._decode_inflight
-                self._decode_inflight = None
-                newer = {seq.seq_id for _, seq in pairs} if pairs is not None else ()
-                outputs += self._apply_deferred(previous, outs_prev, pairs_prev, still_running=newer)
-            if pairs is not None:
-                self._launch_bookkeeping(pairs)
-                self._decode_inflight = (outs_d, pairs)
+            if metas_p:                                        # (its ignored groups are reported when it resolves)
+                self._next_prompt_lane = (lane + 1) % lanes
+                nw = outs_p.blocks_to_nw
+                commands = metas_p
+                if self.staged_prompt_cache:
+                    commands, nw = self._stage_prompt_step(lane, metas_p, outs_p)
+                for slot in outs_p.blocks_to_nw:
+                    self._slot_epoch[(lane, slot)] = self._slot_epoch.get((lane, slot), 0) + 1
+                kwargs = dict(seq_group_metadata_list=commands, blocks_to_swap_in={}, blocks_to_swap_out={},
+                              blocks_to_copy={}, blocks_to_nw=nw,
+                              nw_epochs={s: self._slot_epoch[(lane, s)] for s in outs_p.blocks_to_nw})
+                pending = ex.launch_prompt(kwargs, lane) if lane else ex.launch_prompt(kwargs)
+                outs_p.scheduled_seq_groups = list(outs_p.scheduled_seq_groups)
+                self._prompt_inflight = (pending, outs_p, [m.request_id for m in metas_p], lane)
+                progressed = True
+        # ---- token pools: start every pool's next step, then collect every pool's previous one
+        started: List[Optional[tuple]] = [None] * lanes
+        asked = [False] * lanes
+        for lane in range(lanes):
+            metas_d, outs_d = self.schedulers[lane].schedule_decodes()
+            decode_kwargs = None
+            if metas_d:
+                pairs = [(g, g.get_seqs(status=SequenceStatus.RUNNING)[0]) for g in outs_d.scheduled_seq_groups]
+                decode_kwargs = dict(seq_group_metadata_list=metas_d, blocks_to_swap_in=outs_d.blocks_to_swap_in,
+                                     blocks_to_swap_out=outs_d.blocks_to_swap_out, blocks_to_copy=outs_d.blocks_to_copy,
+                                     blocks_to_nw=outs_d.blocks_to_nw,
+                                     nw_epochs={s: self._slot_epoch.get((lane, s), 0) for s in outs_d.blocks_to_nw})
+                started[lane] = (outs_d, pairs)
+            if decode_kwargs is not None or self._decode_inflight[lane] is not None:
+                if lanes == 1:
+                    ex.decode_send(decode_kwargs)
+                else:
+                    ex.decode_send(decode_kwargs, lane)
+                asked[lane] = True
+        for lane in range(lanes):
+            if not asked[lane]:
+                continue
+            previous = ex.decode_collect() if lanes == 1 else ex.decode_collect(lane)
+            if self._decode_inflight[lane] is not None:
+                outs_prev, pairs_prev = self._decode_inflight[lane]
+                self._decode_inflight[lane] = None
+                newer = {seq.seq_id for _, seq in started[lane][1]} if started[lane] is not None else ()
+                outputs += self._apply_deferred(previous, outs_prev, pairs_prev, still_running=newer, lane=lane)
+            if started[lane] is not None:
+                self._launch_bookkeeping(started[lane][1], lane)
+                self._decode_inflight[lane] = started[lane]
             progressed = True
         if not progressed and self._prompt_inflight is not None:
             self._prompt_inflight[0].wait()                    # nothing else to do: wait for the prompt step

@@ -16,3 +16,10 @@ class ExecutorBase(ABC):
     @abstractmethod
     def check_health(self) -> None:
         raise NotImplementedError
+
+    def shutdown(self) -> None:
+        """Ends the worker processes an executor has started (none by default)."""
+
+    def kv_bytes_pushed(self) -> int:
+        """Bytes of KV cache pushed prompt pool -> token pool(s) so far (0 without split pools)."""
+        return 0

@@ -22,15 +22,16 @@ def check_block_budget(max_model_len: int, block_size: int, num_gpu_blocks: int)
 class GPUExecutor(ExecutorBase):
     def __init__(self, model_config: ModelConfig, cache_config: CacheConfig, parallel_config: ParallelConfig,
                  scheduler_config: SchedulerConfig, device_config: DeviceConfig,
-                 num_gpu_blocks_override: Optional[int] = None) -> None:
+                 num_gpu_blocks_override: Optional[int] = None, device_index: int = 0, worker_cls=Worker) -> None:
         assert parallel_config.world_size == 1, "GPUExecutor only supports single GPU."
         self.model_config = model_config
         self.cache_config = cache_config
         self.parallel_config = parallel_config
         self.scheduler_config = scheduler_config
         self.device_config = device_config
-        self.driver_worker = Worker(model_config, parallel_config, scheduler_config, device_config,
-                                    kv_cache_dtype=cache_config.cache_dtype, is_driver_worker=True)
+        self.driver_worker = worker_cls(model_config, parallel_config, scheduler_config, device_config,
+                                        local_rank=device_index, kv_cache_dtype=cache_config.cache_dtype,
+                                        is_driver_worker=True)
         self.driver_worker.init_model()
         self.driver_worker.load_model()
         self._init_cache(num_gpu_blocks_override)

@@ -17,8 +17,11 @@ class InputMetadata:
     block_tables: Optional[torch.Tensor]          # int32 [num_seqs, max_blocks]
     use_cuda_graph: bool
     kv_cache_dtype: str
-    # {hand-off slot: [(first block, number of blocks), ...]} to push (prompt pool) or await (token pool)
-    blocks_to_nw: Dict[int, List[Tuple[int, int]]] = field(default_factory=dict)
+    # {hand-off slot: [(first block, number of blocks), ...]} to push (prompt pool) or await (token pool);
+    # a prompt pool with block numbers of its own pushes (first source block, first destination block, number)
+    blocks_to_nw: Dict[int, List[Tuple[int, ...]]] = field(default_factory=dict)
+    # the token pool that this prompt step's sequences decode on (prompt pools that feed several)
+    nw_peer: int = 0
     # mean context of an eagerly run decode step (None: unknown, e.g. inside a captured graph)
     mean_context_len: Optional[float] = None
     # "v1" / "v2": the decode-attention kernel to use whatever the dispatch rule says (captured graphs exist in

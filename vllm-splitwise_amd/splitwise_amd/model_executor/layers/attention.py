@@ -193,7 +193,12 @@ class Attention(nn.Module):
                 comm = self.kvcache_comm_manager
                 if hasattr(comm, "put_many"):
                     # every run of every hand-off slot, K and V, in one launch per layer
-                    comm.put_many(self.layer_id, [r for runs in input_metadata.blocks_to_nw.values() for r in runs])
+                    runs = [r for slot_runs in input_metadata.blocks_to_nw.values() for r in slot_runs]
+                    peer = getattr(input_metadata, "nw_peer", 0)
+                    if peer:
+                        comm.put_many(self.layer_id, runs, peer)
+                    else:
+                        comm.put_many(self.layer_id, runs)
                 else:
                     for sem_id, runs in input_metadata.blocks_to_nw.items():
                         for block_start, num_blocks in runs:

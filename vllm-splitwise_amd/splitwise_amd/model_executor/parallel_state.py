@@ -19,7 +19,7 @@ _HOST_STAGED = False      # gloo stand-in for tests: collectives run on host cop
 
 
 def initialize_model_parallel(tensor_model_parallel_size: int = 1, sep_prompt_token: bool = False,
-                              backend: Optional[str] = None) -> None:
+                              backend: Optional[str] = None, token_pools: int = 1) -> None:
     global _TP_GROUP, _STAGE_GROUP, _TP_WORLD, _TP_RANK, _HOST_STAGED
     if tensor_model_parallel_size == 1:
         # pools of one GPU need no collective at all; creating one-member groups would only add
@@ -40,8 +40,10 @@ def initialize_model_parallel(tensor_model_parallel_size: int = 1, sep_prompt_to
             _TP_RANK = ranks.index(rank)
     _TP_WORLD = tensor_model_parallel_size
     if sep_prompt_token:
-        half = world // 2
-        for ranks in (list(range(0, half)), list(range(half, world))):
+        # the prompt pool, then the token pool(s): the reference has one of each, half the world each
+        pool = world // (1 + token_pools)
+        for first in range(0, world, pool):
+            ranks = list(range(first, first + pool))
             group = dist.new_group(ranks, backend=backend)
             if rank in ranks:
                 _STAGE_GROUP = group

@@ -74,6 +74,20 @@ def coalesce_blocks_by_id(blocks_by_slot: Dict[int, List[int]]) -> Dict[int, Lis
     return blocks_by_slot
 
 
+def coalesce_block_pairs(src_blocks: List[int], dst_blocks: List[int]) -> List[Tuple[int, int, int]]:
+    """Block i of ``src_blocks`` goes to block i of ``dst_blocks``: maximal runs (src start, dst start, length)
+    over which BOTH sides are consecutive, in table order.  The counterpart of ``coalesce_blocks`` for a prompt
+    pool whose block numbers differ from the token pool's."""
+    assert len(src_blocks) == len(dst_blocks)
+    runs: List[Tuple[int, int, int]] = []
+    for src, dst in zip(src_blocks, dst_blocks):
+        if runs and runs[-1][0] + runs[-1][2] == src and runs[-1][1] + runs[-1][2] == dst:
+            runs[-1] = (runs[-1][0], runs[-1][1], runs[-1][2] + 1)
+        else:
+            runs.append((src, dst, 1))
+    return runs
+
+
 def random_uuid() -> str:
     return uuid.uuid4().hex
 

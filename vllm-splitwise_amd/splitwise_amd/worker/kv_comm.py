@@ -103,19 +103,33 @@ def slab_layout(num_layers: int, key_block_bytes: int, num_blocks: int,
     return offsets, total - FLAG_BYTES, total
 
 
-class KVCacheCommunicator:
-    """The data path once both sides are connected (comm_utils.py:90-147)."""
+class PeerCache:
+    """The paired worker's cache slab as this process sees it."""
 
-    def __init__(self, block_size: int, layer_offsets: List[Tuple[int, int]], local_base: int, peer_base: int,
-                 flags_offset: int, transport: str, device: torch.device, peer_is_remote: bool = True) -> None:
+    def __init__(self, base: int, layer_offsets: List[Tuple[int, int]], flags_offset: int, num_blocks: int,
+                 remote: bool) -> None:
+        self.base = base                          # the IPC mapping (0 on the token side, which never pushes)
+        self.layer_offsets = layer_offsets        # byte offsets of every layer's (K, V) tensor in the PEER's slab
+        self.flags_offset = flags_offset
+        self.num_blocks = num_blocks
+        self.remote = remote                      # on another device (a link in between) or on this one
+        self.bytes: Optional[torch.Tensor] = None  # runtime transport: the mapping as a tensor
+        self.signal_epoch = [0] * MAX_SLOT_IDS
+
+
+class KVCacheCommunicator:
+    """The data path once both sides are connected (comm_utils.py:90-147).  A prompt worker may feed
+    several token workers (``peers``; the reference has exactly one, :165)."""
+
+    def __init__(self, block_size: int, layer_offsets: List[Tuple[int, int]], local_base: int,
+                 peers: List[PeerCache], flags_offset: int, transport: str, device: torch.device) -> None:
         self.block_size = block_size                  # bytes of one block of one tensor
         self.layer_offsets = layer_offsets
         self.local_base = local_base
-        self.peer_base = peer_base
+        self.peers = peers
         self.flags_offset = flags_offset
         self.transport = transport
         self.device = device
-        self.signal_epoch = [0] * MAX_SLOT_IDS
         self.wait_epoch = [0] * MAX_SLOT_IDS
         self.bytes_pushed = 0
         # where a wait that ran out of its spin bound leaves 1 + slot: a word of pinned host memory that the
@@ -132,10 +146,22 @@ class KVCacheCommunicator:
         self.push_stream = torch.cuda.Stream(device) if device.type == "cuda" else None
         # workgroups of one push launch: a link is filled by a few dozen, a device-local copy (both
         # workers on one GPU: tests, rehearsals) wants one per 64 KiB chunk
-        self.push_workgroups = int(os.environ.get("SPLITWISE_KV_PUSH_WORKGROUPS", "32" if peer_is_remote else "0"))
+        env = os.environ.get("SPLITWISE_KV_PUSH_WORKGROUPS")
+        self.push_workgroups = [int(env) if env is not None else (32 if p.remote else 0) for p in peers]
         # runtime transport state
         self.local_bytes: Optional[torch.Tensor] = None
-        self.peer_bytes: Optional[torch.Tensor] = None
+
+    # the single-peer names of earlier callers
+    @property
+    def peer_base(self) -> int:
+        return self.peers[0].base
+
+    @property
+    def signal_epoch(self) -> List[int]:
+        return self.peers[0].signal_epoch
+
+    def peer_num_blocks(self, peer: int = 0) -> int:
+        return self.peers[peer].num_blocks
 
     def _stream(self) -> int:
         return torch.cuda.current_stream(self.device).cuda_stream
@@ -164,44 +190,54 @@ class KVCacheCommunicator:
         event.record(self.push_stream)
         return event
 
-    def put_many(self, layer_id: int, runs: Sequence[Tuple[int, int]]) -> None:
-        """All (block_start, num_blocks) runs of one layer, K and V, in one launch."""
+    def put_many(self, layer_id: int, runs: Sequence[Tuple[int, ...]], peer: int = 0) -> None:
+        """All runs of one layer, K and V, in one launch.  A run is (block_start, num_blocks) -- the same
+        block numbers on both sides, as in the reference -- or (src_block_start, dst_block_start, num_blocks)
+        when the prompt side numbers its blocks by itself."""
         if not runs:
             return
-        k_off, v_off = self.layer_offsets[layer_id]
-        offsets, sizes = [], []
-        for block_start, num_blocks in runs:
-            for base in (k_off, v_off):
-                offsets.append(base + block_start * self.block_size)
+        target = self.peers[peer]
+        k_src, v_src = self.layer_offsets[layer_id]
+        k_dst, v_dst = target.layer_offsets[layer_id]
+        src_offsets, dst_offsets, sizes = [], [], []
+        for run in runs:
+            src_start, dst_start, num_blocks = (run[0], run[0], run[1]) if len(run) == 2 else run
+            if (min(src_start, dst_start, num_blocks) < 0 or dst_start + num_blocks > target.num_blocks):
+                raise RuntimeError(f"KV push of blocks {src_start}..+{num_blocks} -> {dst_start} is outside the peer's "
+                                   f"cache of {target.num_blocks} blocks")
+            for src_base, dst_base in ((k_src, k_dst), (v_src, v_dst)):
+                src_offsets.append(src_base + src_start * self.block_size)
+                dst_offsets.append(dst_base + dst_start * self.block_size)
                 sizes.append(num_blocks * self.block_size)
         self.bytes_pushed += sum(sizes)
         stream = self._after_compute()
         if self.transport == "kernel":
-            _C.kv_ops.kv_push(self.peer_base, self.local_base, offsets, sizes, stream.cuda_stream,
-                              self.push_workgroups)
+            _C.kv_ops.kv_push_mapped(target.base, self.local_base, dst_offsets, src_offsets, sizes,
+                                     stream.cuda_stream, self.push_workgroups[peer])
         else:
             with torch.cuda.stream(stream):
-                for off, n in zip(offsets, sizes):
-                    self.peer_bytes[off:off + n].copy_(self.local_bytes[off:off + n], non_blocking=True)
+                for dst, src, n in zip(dst_offsets, src_offsets, sizes):
+                    target.bytes[dst:dst + n].copy_(self.local_bytes[src:src + n], non_blocking=True)
 
     def put(self, sem_id: int, layer_id: int, block_start: int, num_blocks: int) -> None:
         del sem_id                                    # ordering is by stream, not by channel
         self.put_many(layer_id, [(block_start, num_blocks)])
 
-    def signal_and_flush(self, sem_id: int, epoch: Optional[int] = None) -> None:
+    def signal_and_flush(self, sem_id: int, epoch: Optional[int] = None, peer: int = 0) -> None:
+        target = self.peers[peer]
         if epoch is None:
-            epoch = self.signal_epoch[sem_id] + 1
-        self.signal_epoch[sem_id] = epoch
+            epoch = target.signal_epoch[sem_id] + 1
+        target.signal_epoch[sem_id] = epoch
         # on the push stream, behind every push of the step (each of which waited for its layer's cache
         # write): the hand-off is announced when the last layer's blocks have left, not when the
         # prompt step's remaining layers, logits and sampling are over
         if self.transport == "kernel":
-            _C.kv_ops.kv_signal(self.peer_base + self.flags_offset, sem_id, epoch, self.push_stream.cuda_stream)
+            _C.kv_ops.kv_signal(target.base + target.flags_offset, sem_id, epoch, self.push_stream.cuda_stream)
         else:
             word = torch.tensor([epoch], dtype=torch.int32, device=self.device).view(torch.uint8)
-            off = self.flags_offset + 4 * sem_id
+            off = target.flags_offset + 4 * sem_id
             with torch.cuda.stream(self._after_compute()):               # `word` was made on the compute stream
-                self.peer_bytes[off:off + 4].copy_(word, non_blocking=True)      # after the data copies, in stream order
+                target.bytes[off:off + 4].copy_(word, non_blocking=True)      # after the data copies, in stream order
             word.record_stream(self.push_stream)
 
     def wait(self, sem_id: int, epoch: Optional[int] = None) -> None:
@@ -224,25 +260,40 @@ class KVCacheCommunicator:
 class KVCacheCommManager:
     """``init`` carries what the reference's ``mscclpp_init_method`` stands for: how to reach the
     peer.  Keys: ``exchange`` -- callable(obj) -> the paired worker's obj (a symmetric swap over
-    any control channel); ``transport`` -- "kernel" (default) or "runtime"."""
+    any control channel; a prompt worker with several token pools is called as exchange(obj, peer_index));
+    ``transport`` -- "kernel" (default) or "runtime".
+
+    World layout: ranks 0..n-1 are the prompt pool (n = num_prompt_workers), followed by one or more
+    token pools of n ranks each.  Prompt rank r is paired with rank r of EVERY token pool; with one token
+    pool that is the reference's (rank + n) % world (comm_utils.py:165)."""
 
     def __init__(self, rank: int, world_size: int, num_prompt_workers: int, init: Dict) -> None:
         self.rank = rank
         self.world_size = world_size
         self.num_prompt_workers = num_prompt_workers
-        self.corr_worker_rank = (rank + num_prompt_workers) % world_size
         self.is_prompt_side = rank < num_prompt_workers
+        n = num_prompt_workers
+        if self.is_prompt_side:
+            self.peer_ranks = list(range(rank + n, world_size, n))
+        else:
+            self.peer_ranks = [rank % n]
+        self.corr_worker_rank = self.peer_ranks[0]
         self.exchange: Callable = init["exchange"]
         self.transport: str = init.get("transport", "kernel")
         if self.transport not in ("kernel", "runtime"):
             raise ValueError(f"unknown KV transport {self.transport!r}")
         self.kvcache_comm: Optional[KVCacheCommunicator] = None
-        self._peer_mapping: Optional[int] = None
+        self._peer_mappings: List[int] = []
         self._slab: Optional[torch.Tensor] = None
+
+    def _swap(self, obj, peer_index: int):
+        if len(self.peer_ranks) == 1:
+            return self.exchange(obj)
+        return self.exchange(obj, peer_index)
 
     def setup_comm(self, num_layers: int, kv_cache: List[Tuple[torch.Tensor, torch.Tensor]]) -> None:
         """Registers every layer's K and V tensor (they must be views of one slab, see
-        ``CacheEngine``) and connects to the peer."""
+        ``CacheEngine``) and connects to the peer(s)."""
         k0 = kv_cache[0][0]
         slab = getattr(k0, "_slab", None)
         if slab is None:
@@ -266,36 +317,41 @@ class KVCacheCommManager:
         slab[flags_offset:].zero_()
         torch.cuda.synchronize(device)
         info = {"rank": self.rank, "nbytes": slab.numel(), "layer_offsets": layer_offsets,
+                "block_bytes": block_bytes, "num_blocks": int(k0.shape[0]), "flags_offset": flags_offset,
                 "handle": _C.kv_ops.ipc_get_mem_handle(alloc_base), "offset": base - alloc_base,
                 "pid_device": (torch.cuda.current_device(),)}
-        peer = self.exchange(info)
-        if peer["rank"] != self.corr_worker_rank:
-            raise RuntimeError(f"KV transport paired rank {self.rank} with {peer['rank']}, expected "
-                               f"{self.corr_worker_rank}")
-        if peer["nbytes"] != info["nbytes"] or peer["layer_offsets"] != layer_offsets:
-            raise RuntimeError("prompt and token workers disagree on the cache layout")
-        peer_base = 0
-        if self.is_prompt_side:
-            mapped = _bounded(lambda: _C.kv_ops.ipc_open_mem_handle(peer["handle"]), _IPC_OPEN_TIMEOUT_S,
-                              "mapping the token worker's KV cache (hipIpcOpenMemHandle)")
-            self._peer_mapping = mapped
-            peer_base = mapped + peer["offset"]
-        remote = tuple(peer.get("pid_device", ())) != (torch.cuda.current_device(),)
-        comm = KVCacheCommunicator(block_bytes, layer_offsets, base, peer_base, flags_offset, self.transport, device,
-                                   peer_is_remote=remote)
+        peers: List[PeerCache] = []
+        for index, peer_rank in enumerate(self.peer_ranks):
+            peer = self._swap(info, index)
+            if peer["rank"] != peer_rank:
+                raise RuntimeError(f"KV transport paired rank {self.rank} with {peer['rank']}, expected {peer_rank}")
+            if peer["block_bytes"] != block_bytes or len(peer["layer_offsets"]) != num_layers:
+                raise RuntimeError("prompt and token workers disagree on the cache layout (bytes per block, layers)")
+            peer_base = 0
+            if self.is_prompt_side:
+                mapped = _bounded(lambda h=peer["handle"]: _C.kv_ops.ipc_open_mem_handle(h), _IPC_OPEN_TIMEOUT_S,
+                                  "mapping the token worker's KV cache (hipIpcOpenMemHandle)")
+                self._peer_mappings.append(mapped)
+                peer_base = mapped + peer["offset"]
+            remote = tuple(peer.get("pid_device", ())) != (torch.cuda.current_device(),)
+            view = PeerCache(peer_base, [tuple(o) for o in peer["layer_offsets"]], peer["flags_offset"],
+                             peer["num_blocks"], remote)
+            if self.transport == "runtime" and self.is_prompt_side:
+                view.bytes = torch.as_tensor(_DevicePtrView(peer_base, peer["nbytes"]), device=device)
+            peers.append(view)
+        comm = KVCacheCommunicator(block_bytes, layer_offsets, base, peers, flags_offset, self.transport, device)
         if self.transport == "runtime":
             comm.local_bytes = slab
-            if self.is_prompt_side:
-                comm.peer_bytes = torch.as_tensor(_DevicePtrView(peer_base, slab.numel()), device=device)
         self.kvcache_comm = comm
-        self.exchange({"rank": self.rank, "ready": True})        # both sides mapped before any put
+        for index in range(len(self.peer_ranks)):
+            self._swap({"rank": self.rank, "ready": True}, index)        # both sides mapped before any put
 
     def destroy_comm(self) -> None:
         if self.kvcache_comm is not None:
             torch.cuda.synchronize(self.kvcache_comm.device)
-        if self._peer_mapping is not None:
-            _C.kv_ops.ipc_close_mem_handle(self._peer_mapping)
-            self._peer_mapping = None
+        for mapped in self._peer_mappings:
+            _C.kv_ops.ipc_close_mem_handle(mapped)
+        self._peer_mappings = []
         self.kvcache_comm = None
 
     def check_status(self) -> None:
@@ -315,14 +371,14 @@ class KVCacheCommManager:
     def wait(self, sem_id: int, epoch: Optional[int] = None) -> None:
         self.kvcache_comm.wait(sem_id, epoch)
 
-    def signal_and_flush(self, sem_id: int, epoch: Optional[int] = None) -> None:
-        self.kvcache_comm.signal_and_flush(sem_id, epoch)
+    def signal_and_flush(self, sem_id: int, epoch: Optional[int] = None, peer: int = 0) -> None:
+        self.kvcache_comm.signal_and_flush(sem_id, epoch, peer)
 
     def put(self, sem_id: int, layer_id: int, block_start: int, num_blocks: int) -> None:
         self.kvcache_comm.put(sem_id, layer_id, block_start, num_blocks)
 
-    def put_many(self, layer_id: int, runs: Sequence[Tuple[int, int]]) -> None:
-        self.kvcache_comm.put_many(layer_id, runs)
+    def put_many(self, layer_id: int, runs: Sequence[Tuple[int, ...]], peer: int = 0) -> None:
+        self.kvcache_comm.put_many(layer_id, runs, peer)
 
     def pushes_done_event(self):
         return self.kvcache_comm.pushes_done_event() if self.kvcache_comm is not None else None

@@ -291,7 +291,7 @@ class ModelRunner:
     # --------------------------------------------------------------- execution
     @torch.inference_mode()
     def execute_model(self, metas: List[SequenceGroupMetadata], kv_caches, blocks_to_nw=None,
-                      prompt_layout: str = "packed", defer: bool = False):
+                      prompt_layout: str = "packed", defer: bool = False, nw_peer: int = 0):
         """``defer``: return the step's ``PendingSamples`` (tokens still on the device) instead of a
         ``SamplerOutput``; the next decode step takes unknown last tokens from it."""
         is_prompt = metas[0].is_prompt
@@ -312,6 +312,7 @@ class ModelRunner:
             tokens, positions, md = self._prepare_decode(metas)
             sampling_md = self._prepare_sample(metas, None)
         md.blocks_to_nw = blocks_to_nw or {}
+        md.nw_peer = nw_peer
         # the model sees one flat token dimension in every layout
         if md.use_cuda_graph:
             runners = self.graph_runners_partitioned if md.decode_kernel == "v2" else self.graph_runners

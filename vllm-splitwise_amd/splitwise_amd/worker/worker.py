@@ -96,7 +96,8 @@ class Worker:
             warm = torch.zeros(1, device="cpu" if dist.get_backend() == "gloo" else self.device)
             dist.all_reduce(warm)                                      # warm-up (worker.py:452-455)
         parallel_state.initialize_model_parallel(self.parallel_config.tensor_parallel_size,
-                                                 self.parallel_config.sep_prompt_token)
+                                                 self.parallel_config.sep_prompt_token,
+                                                 token_pools=max(self.parallel_config.num_token_pools, 1))
         if (self.parallel_config.tensor_parallel_size > 1
                 and not getattr(self.parallel_config, "disable_custom_all_reduce", False)):
             # worker.py:100-103 of the reference: small all-reduces go through direct peer reads
@@ -203,10 +204,11 @@ class Worker:
                       blocks_to_swap_out: Optional[Dict[int, int]] = None,
                       blocks_to_copy: Optional[Dict[int, List[int]]] = None,
                       blocks_to_nw: Optional[Dict[int, List[Tuple[int, int]]]] = None,
-                      nw_epochs: Optional[Dict[int, int]] = None, defer: bool = False):
+                      nw_epochs: Optional[Dict[int, int]] = None, defer: bool = False, nw_peer: int = 0):
         """``defer`` leaves the sampled tokens on the device (see ModelRunner.execute_model).
         ``nw_epochs`` (optional) gives the hand-off count of every slot in ``blocks_to_nw`` as the
-        engine counts it; without it each side counts its own signals / waits."""
+        engine counts it; without it each side counts its own signals / waits.  ``nw_peer`` (prompt
+        workers that feed several token pools): the pool this step's sequences will decode on."""
         blocks_to_nw = blocks_to_nw or {}
         nw_epochs = nw_epochs or {}
         self.cache_swap(blocks_to_swap_in or {}, blocks_to_swap_out or {}, blocks_to_copy or {})
@@ -217,10 +219,14 @@ class Worker:
         if blocks_to_nw and comm is not None and self.is_token_worker() and not is_prompt:
             for sem_id in blocks_to_nw:
                 comm.wait(sem_id, nw_epochs.get(sem_id))
-        output = self.model_runner.execute_model(seq_group_metadata_list, self.gpu_cache, blocks_to_nw, defer=defer)
+        output = self.model_runner.execute_model(seq_group_metadata_list, self.gpu_cache, blocks_to_nw, defer=defer,
+                                                 nw_peer=nw_peer)
         if blocks_to_nw and comm is not None and self.is_prompt_worker() and is_prompt:
             for sem_id in blocks_to_nw:
-                comm.signal_and_flush(sem_id, nw_epochs.get(sem_id))
+                if nw_peer:
+                    comm.signal_and_flush(sem_id, nw_epochs.get(sem_id), nw_peer)
+                else:
+                    comm.signal_and_flush(sem_id, nw_epochs.get(sem_id))
             # the pushes and signals run on the transport's own stream: the step is over when they have left
             # too (its blocks may be handed out again as soon as it is reported finished)
             pushed = comm.pushes_done_event() if hasattr(comm, "pushes_done_event") else None
