@@ -63,22 +63,27 @@ class _FakeRunner:
 
 
 class FakeWorker:
-    def __init__(self, model_config, parallel_config, scheduler_config, device_config, local_rank, rank,
-                 kv_cache_dtype, is_driver_worker, kv_transport_init, distributed_init_method=None,
+    def __init__(self, model_config, parallel_config, scheduler_config, device_config, local_rank=0, rank=0,
+                 kv_cache_dtype="auto", is_driver_worker=True, kv_transport_init=None, distributed_init_method=None,
                  distributed_store=None) -> None:
         self.rank = rank
         self.parallel_config = parallel_config
         self.tp = parallel_config.tensor_parallel_size
-        self.world = 2 * self.tp
-        self.peer = (rank + self.tp) % self.world
-        self.is_prompt = rank < self.tp
+        self.world = parallel_config.world_size            # tp * (1 + token pools)
+        self.mixed = not parallel_config.sep_prompt_token      # co-located: one pool does both kinds of step
+        self.is_prompt = rank < self.tp and not self.mixed
+        # a prompt rank is paired with the same rank of every token pool, a token rank with its prompt rank
+        self.peers = list(range(rank + self.tp, self.world, self.tp)) if self.is_prompt else [rank % self.tp]
+        self.peer = self.peers[0]
+        self.staged = bool(getattr(parallel_config, "staged_prompt_cache", False))
         self.distributed_init_method = distributed_init_method
         self.distributed_store = distributed_store
-        self.exchange = kv_transport_init["exchange"]
-        self.dir = os.environ["SPLIT_FAKE_DIR"]
+        self.exchange = kv_transport_init["exchange"] if kv_transport_init else None
+        self.dir = os.environ.get("SPLITWISE_DRYRUN_DIR") or os.environ["SPLIT_FAKE_DIR"]
         self.model_runner = _FakeRunner()
-        self.kvcache_comm_manager = _FakeCommManager()
-        self.cache = self.flags = self.peer_cache = self.peer_flags = None
+        self.kvcache_comm_manager = _FakeCommManager() if not self.mixed else None
+        self.cache = self.flags = None
+        self.peer_caches, self.peer_flag_arrays = [], []
         self.block_size = 16
         self.log: List[str] = []
 
@@ -99,7 +104,8 @@ class FakeWorker:
         else:
             dist.init_process_group("gloo", world_size=self.world, rank=self.rank, timeout=timeout,
                                     init_method=self.distributed_init_method)
-        parallel_state.initialize_model_parallel(self.tp, True)
+        parallel_state.initialize_model_parallel(self.tp, not self.mixed,
+                                                 token_pools=max(self.parallel_config.num_token_pools, 1))
         assert parallel_state.get_tensor_model_parallel_rank() == self.rank % self.tp
 
     def _agree(self, token: int) -> int:
@@ -139,14 +145,23 @@ class FakeWorker:
         pass
 
     def setup_kvcache_comm(self) -> None:
+        if self.mixed:
+            return
         if os.environ.get("SPLIT_FAKE_DIE_IN_HANDSHAKE") == str(self.rank):
             os._exit(3)                                    # a worker that dies before it has handed anything in
-        peer = self.exchange({"rank": self.rank, "blocks": int(self.cache.shape[0])})
-        assert peer["rank"] == self.peer and peer["blocks"] == self.cache.shape[0], peer
-        if self.is_prompt:
-            self.peer_cache = np.load(os.path.join(self.dir, f"cache{self.peer}.npy"), mmap_mode="r+")
-            self.peer_flags = np.load(os.path.join(self.dir, f"flags{self.peer}.npy"), mmap_mode="r+")
-        self.exchange({"rank": self.rank, "ready": True})
+        def swap(obj, index):
+            return self.exchange(obj) if len(self.peers) == 1 else self.exchange(obj, index)
+
+        for index, peer_rank in enumerate(self.peers):
+            peer = swap({"rank": self.rank, "blocks": int(self.cache.shape[0])}, index)
+            assert peer["rank"] == peer_rank, peer
+            # without staging a block number means the same block on both sides: equal sizes
+            assert self.staged or peer["blocks"] == self.cache.shape[0], peer
+            if self.is_prompt:
+                self.peer_caches.append(np.load(os.path.join(self.dir, f"cache{peer_rank}.npy"), mmap_mode="r+"))
+                self.peer_flag_arrays.append(np.load(os.path.join(self.dir, f"flags{peer_rank}.npy"), mmap_mode="r+"))
+        for index in range(len(self.peers)):
+            swap({"rank": self.rank, "ready": True}, index)
 
     def destroy_kvcache_comm(self) -> None:
         pass
@@ -159,17 +174,17 @@ class FakeWorker:
         return [int(self.cache[block_table[i // self.block_size], i % self.block_size]) for i in range(n)]
 
     def execute_model(self, seq_group_metadata_list=None, blocks_to_swap_in=None, blocks_to_swap_out=None,
-                      blocks_to_copy=None, blocks_to_nw=None, nw_epochs=None, defer=False):
-        out = self._execute(seq_group_metadata_list, blocks_to_nw, nw_epochs)
+                      blocks_to_copy=None, blocks_to_nw=None, nw_epochs=None, defer=False, nw_peer=0):
+        out = self._execute(seq_group_metadata_list, blocks_to_nw, nw_epochs, nw_peer)
         # like the device, this worker remembers the tokens it sampled last: a deferred step's tokens
         # reach the engine one call later, and the next command names them by a placeholder (-1)
         self._last_samples = {g.samples[0].parent_seq_id: g.samples[0].output_token for g in out}
         return _Deferred(out) if defer else out
 
-    def _execute(self, seq_group_metadata_list, blocks_to_nw, nw_epochs) -> SamplerOutput:
+    def _execute(self, seq_group_metadata_list, blocks_to_nw, nw_epochs, nw_peer=0) -> SamplerOutput:
         blocks_to_nw = blocks_to_nw or {}
         outputs = []
-        if self.is_prompt:
+        if self.is_prompt or (self.mixed and seq_group_metadata_list[0].is_prompt):
             for meta in seq_group_metadata_list:
                 assert meta.is_prompt
                 (seq_id, data), = meta.seq_data.items()
@@ -179,14 +194,20 @@ class FakeWorker:
                     self._write(table, pos, tok)
                 tok = self._agree(next_token(tokens))
                 outputs.append(SequenceGroupOutput([SequenceOutput(seq_id, tok, {tok: Logprob(0.0)})]))
+            if self.mixed:
+                return SamplerOutput(outputs)
             time.sleep(0.002)                              # the decode step on the other side overlaps this one
+            peer_cache, peer_flags = self.peer_caches[nw_peer], self.peer_flag_arrays[nw_peer]
             for slot, runs in blocks_to_nw.items():
-                for start, count in runs:
-                    self.peer_cache[start:start + count] = self.cache[start:start + count]
+                for run in runs:                           # (start, count), or (source start, destination start, count)
+                    src, dst, count = (run[0], run[0], run[1]) if len(run) == 2 else run
+                    peer_cache[dst:dst + count] = self.cache[src:src + count]
                     self.kvcache_comm_manager.kvcache_comm.bytes_pushed += count * self.block_size * 8
-                self.peer_cache.flush()
-                self.peer_flags[slot] = nw_epochs[slot]    # signal after the data
-                self.peer_flags.flush()
+                peer_cache.flush()
+                peer_flags[slot] = nw_epochs[slot]         # signal after the data
+                peer_flags.flush()
+            if self.staged:
+                self.cache[:] = -7                         # a staged prompt cache keeps nothing between steps
             return SamplerOutput(outputs)
         # token side: wait for every hand-off this step depends on, then decode from the cache
         for slot in blocks_to_nw:

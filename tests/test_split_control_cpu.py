@@ -11,14 +11,15 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 
-def _rank_main(rank: int, init_method: str, tmpdir: str, result_path: str, blocks: int, pipeline: bool) -> None:
+def _rank_main(rank: int, init_method: str, tmpdir: str, result_path: str, blocks: int, pipeline: bool,
+               token_pools: int = 1, staged: bool = False) -> None:
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     sys.path.insert(0, here)
     import conftest  # noqa: F401  (adds the package and the repo root to sys.path)
     os.environ["SPLIT_FAKE_DIR"] = tmpdir
     os.environ["SPLIT_FAKE_BLOCKS"] = str(blocks)
-    dist.init_process_group("gloo", init_method=init_method, rank=rank, world_size=2)
+    dist.init_process_group("gloo", init_method=init_method, rank=rank, world_size=1 + token_pools)
     from split_fakes import VOCAB, FakeWorker, next_token
     from splitwise_amd import EngineArgs, LLMEngine, SamplingParams
     from splitwise_amd.executor.channel import DistChannel
@@ -26,18 +27,27 @@ def _rank_main(rank: int, init_method: str, tmpdir: str, result_path: str, block
     from splitwise_amd.executor.splitwise_executor import SplitwiseExecutor
 
     args = EngineArgs(model="llama-tiny", sep_prompt_token=True, max_num_seqs=6, max_model_len=128,
-                      max_num_batched_tokens=512, swap_space=0.001, pipeline_steps=pipeline)
+                      max_num_batched_tokens=512, swap_space=0.001, pipeline_steps=pipeline,
+                      token_pools=token_pools, staged_prompt_cache=staged)
     mc, cc, pc, sc, dc = args.create_engine_configs()
-    if rank == 1:
-        cfg = {"model_config": mc, "parallel_config": pc, "scheduler_config": sc, "cache_config": cc, "rank": 1,
+    assert pc.world_size == 1 + token_pools and pc.staged_prompt_cache == (staged or token_pools > 1)
+    if rank >= 1:
+        cfg = {"model_config": mc, "parallel_config": pc, "scheduler_config": sc, "cache_config": cc, "rank": rank,
                "local_rank": 0, "transport": "kernel"}
         worker_loop(DistChannel(0), cfg, worker_cls=FakeWorker)
         dist.barrier()
         return
-    executor = SplitwiseExecutor(mc, cc, pc, sc, dc, channel=DistChannel(1), worker_cls=FakeWorker)
-    assert cc.num_gpu_blocks == blocks                           # the smaller of the two pools
+    executor = SplitwiseExecutor(mc, cc, pc, sc, dc, channels=[DistChannel(1 + j) for j in range(token_pools)],
+                                 worker_cls=FakeWorker)
+    if pc.staged_prompt_cache:
+        # the token pools' size (they offer 16 blocks more than the prompt side), and a prompt cache of two
+        # prompt steps' worth: 512 tokens in at most 6 prompts -> 2 * (32 + 6)
+        assert cc.num_gpu_blocks == blocks + 16 and executor.prompt_cache_blocks == 76
+        blocks = (blocks + 16) * token_pools
+    else:
+        assert cc.num_gpu_blocks == blocks                       # the smaller of the two pools
     engine = LLMEngine(mc, cc, pc, sc, dc, executor=executor)
-    assert engine.pipeline_split == pipeline
+    assert engine.pipeline_split == pipeline and len(engine.schedulers) == token_pools
     rng = random.Random(0)
     prompts = {str(i): [rng.randrange(VOCAB) for _ in range(rng.choice([1, 5, 16, 17, 40, 60]))] for i in range(14)}
     lens = {rid: rng.choice([1, 2, 9, 30, 40]) for rid in prompts}
@@ -79,6 +89,10 @@ def _rank_main(rank: int, init_method: str, tmpdir: str, result_path: str, block
         verdict = f"{blocks - free} cache blocks were never given back"
     if blocks < 64 and preempted == 0:
         verdict = "the small cache did not force a single preemption: the scenario tests nothing"
+    if token_pools > 1 and verdict == "ok":
+        used = [sched.block_manager.gpu_allocator._next_fresh for sched in engine.schedulers]
+        if min(used) == 0:
+            verdict = f"a token pool never received a request: fresh blocks used per pool {used}"
     with open(result_path, "w") as f:
         f.write(verdict)
     dist.barrier()
@@ -93,6 +107,29 @@ def test_split_engine_over_gloo_world_size_2(blocks, pipeline):  # preempted, re
         mp.spawn(_rank_main, args=("file://" + os.path.join(tmp, "rendezvous"), tmp, result, blocks, pipeline),
                  nprocs=2, join=True)
         assert open(result).read() == "ok"
+
+
+@pytest.mark.parametrize("token_pools,staged", [(1, True), (2, True)])
+def test_one_prompt_worker_feeds_token_pools_with_their_own_block_spaces(token_pools, staged):
+    """World size 2 with a staged prompt cache, and world size 3: one prompt worker (rank 0, with the engine)
+    feeding two token workers (ranks 1 and 2).  The prompt side numbers its few blocks by itself and forgets
+    them after every step; each token pool has its own scheduler, block space and hand-off slots.  Every token
+    is computed from what the token worker's cache holds, so a push to the wrong pool, a wrong block mapping
+    or a wrong epoch shows up as a wrong token or a failed wait."""
+    with tempfile.TemporaryDirectory() as tmp:
+        result = os.path.join(tmp, "result.txt")
+        mp.spawn(_rank_main, args=("file://" + os.path.join(tmp, "rendezvous"), tmp, result, 80, True, token_pools,
+                                   staged), nprocs=1 + token_pools, join=True)
+        assert open(result).read() == "ok"
+
+
+def test_block_pair_runs_need_both_sides_consecutive():
+    import conftest  # noqa: F401
+    from splitwise_amd.utils import coalesce_block_pairs
+    assert coalesce_block_pairs([0, 1, 2, 3], [7, 8, 9, 10]) == [(0, 7, 4)]
+    assert coalesce_block_pairs([0, 1, 2, 3], [7, 8, 3, 4]) == [(0, 7, 2), (2, 3, 2)]
+    assert coalesce_block_pairs([4, 5, 9], [1, 2, 3]) == [(4, 1, 2), (9, 3, 1)]
+    assert coalesce_block_pairs([], []) == []
 
 
 def test_slab_layout_is_symmetric_and_avoids_the_unmappable_sizes():

@@ -341,5 +341,5 @@ def compose(args, n: int, plan, summaries: Dict[str, Any], one_gpu: bool, dtype:
         "legs": summaries,
     }
     if not ok:
-        line["error"] = primary.get("error") or primary.get("skipped") or "the headline leg did not run"
+        line["error"] = f"the headline leg ({primary_leg['name']}) did not produce a result: see legs"
     return line

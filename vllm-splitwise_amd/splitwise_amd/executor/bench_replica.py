@@ -64,7 +64,7 @@ def build_engine(spec: Dict[str, Any]):
         model=spec["model"], dtype=spec["dtype"], quantization=spec.get("quantization"),
         kv_cache_dtype=spec.get("kv_cache_dtype", "auto"), sep_prompt_token=split, tensor_parallel_size=tp,
         max_num_seqs=conc, max_model_len=2048, max_num_batched_tokens=spec["max_num_batched_tokens"],
-        num_gpu_blocks_override=int(conc * seq_blocks * 1.25) + 64, swap_space=0.25,
+        num_gpu_blocks_override=max(int(conc * seq_blocks * 1.25) + 64, 2048 // 16 + 8), swap_space=0.25,
         enforce_eager=spec.get("enforce_eager", False), max_context_len_to_capture=1024,
         prefill_batch_tokens=spec["prefill_batch_tokens"], prefill_max_wait=spec["prefill_max_wait"],
         pipeline_steps=spec.get("pipeline_steps", True), token_pools=spec.get("token_pools", 1))
@@ -162,6 +162,12 @@ def _run(spec: Dict[str, Any]) -> None:
     index, replicas, leg = spec["index"], spec["replicas"], spec["leg"]
     fake = bool(spec.get("worker_cls"))
     on_gpu = torch.cuda.is_available() and not fake
+    if fake:
+        # a dry run of the launcher with stand-in workers: they keep their "caches" as files, every replica in
+        # a directory of its own
+        import tempfile
+        scratch = tempfile.mkdtemp(prefix=f"dryrun_{leg}_{index}_", dir=os.path.dirname(spec["result"]))
+        os.environ["SPLITWISE_DRYRUN_DIR"] = scratch
     if on_gpu:
         torch.cuda.set_device(spec["devices"][0])
     barrier = StoreBarrier(spec["store_port"], leg, index, replicas, spec.get("barrier_timeout_s", 900.0))
