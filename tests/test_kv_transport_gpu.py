@@ -57,6 +57,42 @@ def test_push_runs_bit_exact_and_rest_untouched():
     _C.kv_ops.kv_push(dst.data_ptr(), src.data_ptr(), [], [], 0)          # empty: no-op
 
 
+def test_mapped_push_moves_every_range_to_its_own_destination():
+    """sw_kv_push_mapped: a prompt worker that numbers its blocks by itself pushes source range i to
+    destination range i; bytes inside the destination ranges equal their sources, everything else is untouched."""
+    from splitwise_amd import _C
+    torch.manual_seed(1)
+    src = torch.randint(0, 256, (2 * 1024 * 1024,), dtype=torch.uint8, device="cuda")
+    dst = torch.randint(0, 256, (5 * 1024 * 1024 + 48,), dtype=torch.uint8, device="cuda")
+    before = dst.clone()
+    # (source offset, destination offset, bytes): tiny, several chunks, adjacent sources to distant destinations
+    runs = [(0, 4 * 1024 * 1024, 16), (16, 32, 65536 * 2 + 48), (1048576, 3 * 1024 * 1024, 65536),
+            (1048576 + 65536, 1024 * 1024, 131072 + 16), (2 * 1024 * 1024 - 160, 5 * 1024 * 1024 - 112, 160)]
+    stream = torch.cuda.current_stream().cuda_stream
+    for cap in (0, 2):
+        out = before.clone()
+        _C.kv_ops.kv_push_mapped(out.data_ptr(), src.data_ptr(), [d for _, d, _ in runs], [s_ for s_, _, _ in runs],
+                                 [n for _, _, n in runs], stream, cap)
+        torch.cuda.synchronize()
+        expect = before.clone()
+        for s_, d, n in runs:
+            expect[d:d + n] = src[s_:s_ + n]
+        assert torch.equal(out, expect), cap
+    many = [(16 * i, 4096 * i, 16) for i in range(120)]              # more ranges than one launch carries
+    out = before.clone()
+    _C.kv_ops.kv_push_mapped(out.data_ptr(), src.data_ptr(), [d for _, d, _ in many], [s_ for s_, _, _ in many],
+                             [n for _, _, n in many], stream)
+    torch.cuda.synchronize()
+    expect = before.clone()
+    for s_, d, n in many:
+        expect[d:d + n] = src[s_:s_ + n]
+    assert torch.equal(out, expect)
+    with pytest.raises(RuntimeError, match="16-byte"):
+        _C.kv_ops.kv_push_mapped(dst.data_ptr(), src.data_ptr(), [16], [8], [16], 0)
+    with pytest.raises(RuntimeError, match="differ in length"):
+        _C.kv_ops.kv_push_mapped(dst.data_ptr(), src.data_ptr(), [16, 32], [16], [16, 16], 0)
+
+
 def test_signal_then_wait_and_timeout():
     from splitwise_amd import _C
     flags = torch.zeros(260, dtype=torch.int32, device="cuda")
@@ -142,6 +178,89 @@ def test_split_engine_generates_like_the_cpu_model(overlap):
         assert pushed == blocks * 2 * cfg["num_hidden_layers"] * 16 * 2 * 64 * 2      # K+V, bf16... f16 blocks
         # the side that waits is the token worker: its status word is the one that can be set
         llm.llm_engine.model_executor._remote_call("check_kv_status")
+    finally:
+        llm.llm_engine.model_executor.shutdown()
+
+
+def _tokens_agree_with_cpu_model(llm, prompts, outs):
+    from oracle import model as omodel
+    runner = llm.llm_engine.model_executor.driver_worker.model_runner
+    sd = {k: v.detach().cpu() for k, v in runner.model.state_dict().items()}
+    cfg = runner.model_config.hf_config
+    for prompt, out in zip(prompts, outs):
+        gen = out.outputs[0].token_ids
+        ref = omodel.logits("llama", sd, cfg, prompt + gen)
+        for j, tok in enumerate(gen):
+            row = ref[len(prompt) + j - 1]
+            assert row[tok] >= row.max() - 3e-2, (j, tok, int(row.argmax()))
+    return cfg
+
+
+@pytest.mark.parametrize("token_pools", [1, 2])
+def test_staged_prompt_cache_and_two_token_pools_generate_like_the_cpu_model(token_pools):
+    """The prompt worker keeps only the prompts in flight under block numbers of its own (a few blocks where
+    the token workers have 192), and with two token pools feeds two token workers (three processes on the one
+    GPU), each with its own block space and hand-off slots: every decode step still runs on exactly the KV the
+    prompt worker computed, so greedy tokens must agree with the whole-model CPU oracle."""
+    from splitwise_amd import SamplingParams
+    random.seed(2)
+    llm = _split_llm("kernel", pipeline_steps=True, staged_prompt_cache=True, token_pools=token_pools,
+                     max_num_batched_tokens=512)
+    try:
+        engine = llm.llm_engine
+        ex = engine.model_executor
+        assert engine.pipeline_split and len(engine.schedulers) == token_pools
+        assert ex.prompt_cache_blocks == 2 * (512 // 16 + 8)
+        assert ex.driver_worker.gpu_cache[0][0].shape[0] == ex.prompt_cache_blocks
+        prompts = [[random.randrange(512) for _ in range(n)] for n in (5, 33, 64, 17, 100, 1, 16, 48, 7, 90, 31, 65)]
+        outs = llm.generate(prompt_token_ids=prompts, sampling_params=SamplingParams(temperature=0.0, max_tokens=20))
+        assert all(len(o.outputs[0].token_ids) == 20 for o in outs)
+        cfg = _tokens_agree_with_cpu_model(llm, prompts, outs)
+        blocks = sum(-(-len(p) // 16) for p in prompts)
+        assert ex.kv_bytes_pushed() == blocks * 2 * cfg["num_hidden_layers"] * 16 * 2 * 64 * 2
+        for sched in engine.schedulers:
+            assert sched.block_manager.gpu_allocator._next_fresh > 0           # every pool served requests
+            assert sched.block_manager.get_num_free_gpu_blocks() == 192        # ... and got every block back
+        for lane in range(token_pools):
+            ex._remote_call("check_kv_status", lane)
+    finally:
+        llm.llm_engine.model_executor.shutdown()
+
+
+def test_blocks_of_prompts_that_end_at_their_first_token_are_reused_safely():
+    """Requests that finish at their prompt step (max_tokens=1) give their token-side blocks back the moment the
+    step is reported finished, and with a small cache the very next decode step hands them to a running
+    sequence.  The pushes of that prompt step run on the transport's own stream: the step must not be reported
+    finished before they have left, or a late push lands on the new owner's KV.  Tokens of the long sequences
+    must still agree with the CPU model."""
+    from splitwise_amd import LLM, SamplingParams
+    random.seed(3)
+    llm = LLM("llama-tiny", sep_prompt_token=True, enforce_eager=False, num_gpu_blocks_override=40, max_num_seqs=8,
+              max_model_len=512, swap_space=0.01, pipeline_steps=True)
+    try:
+        engine = llm.llm_engine
+        long_prompts = [[random.randrange(512) for _ in range(n)] for n in (30, 45, 17)]
+        short = [[random.randrange(512) for _ in range(random.choice([60, 90, 120]))] for _ in range(24)]
+        params_long = SamplingParams(temperature=0.0, max_tokens=70, ignore_eos=True)
+        params_one = SamplingParams(temperature=0.0, max_tokens=1, ignore_eos=True)
+        for i, p in enumerate(long_prompts):
+            engine.add_request(f"long{i}", None, params_long, prompt_token_ids=p)
+        done, fed, steps = {}, 0, 0
+        while engine.has_unfinished_requests() or fed < len(short):
+            if fed < len(short) and steps % 2 == 0:                  # one-token requests keep arriving
+                engine.add_request(f"one{fed}", None, params_one, prompt_token_ids=short[fed])
+                fed += 1
+            for out in engine.step():
+                if out.finished:
+                    done[out.request_id] = out
+            steps += 1
+            assert steps < 3000
+        assert len(done) == len(long_prompts) + len(short)
+        outs = [done[f"long{i}"] for i in range(len(long_prompts))]
+        assert all(len(o.outputs[0].token_ids) == 70 for o in outs)
+        _tokens_agree_with_cpu_model(llm, long_prompts, outs)
+        ones = [done[f"one{i}"] for i in range(len(short))]
+        _tokens_agree_with_cpu_model(llm, short, ones)
     finally:
         llm.llm_engine.model_executor.shutdown()
 

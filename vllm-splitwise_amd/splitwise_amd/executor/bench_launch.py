@@ -143,6 +143,10 @@ def run_leg(leg: Dict[str, Any], common: Dict[str, Any], store_port: int, workdi
     failure, which ends the others), returns their results."""
     env = {k: v for k, v in os.environ.items() if k not in _TORCHRUN_ENV}
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if os.environ.get("SPLITWISE_BENCH_ONE_GPU") == "1":
+        # RCCL refuses several ranks on one device: the rehearsal's tensor-parallel groups run over gloo (the
+        # all-reduces of up to 8 MiB still go through the peer-read kernel)
+        env.setdefault("SPLITWISE_TP_BACKEND", "gloo")
     procs: List[subprocess.Popen] = []
     logs = []
     n = len(leg["replicas"])
