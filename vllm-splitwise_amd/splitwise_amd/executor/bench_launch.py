@@ -229,6 +229,9 @@ def summarize(leg: Dict[str, Any], results: List[Dict[str, Any]]) -> Dict[str, A
     roof = next((r["roofline"] for r in results if r.get("roofline")), None)
     if roof:
         out["roofline"] = roof
+    probe_errors = [r["probe_error"] for r in results if r.get("probe_error")]
+    if probe_errors:
+        out["probe_error"] = probe_errors[0]
     return out
 
 
@@ -246,9 +249,14 @@ def main(args) -> int:
     dtype = args.dtype or ("float16" if args.quantization else "bfloat16")
     plan = build_plan(n, args.model, dtype, args.legs, args.quantization, args.kv_cache_dtype)
     if one_gpu:               # rehearsal on a one-GPU box: every worker of every replica shares device 0
+        stand_in = os.environ.get("SPLITWISE_BENCH_REHEARSAL_70B", "llama-2-13b")
         for leg in plan:
             for rep in leg["replicas"]:
                 rep["devices"] = [0] * len(rep["devices"])
+                if rep["model"] == "llama-2-70b":
+                    # eight ranks of a 70B model are 280 GB of weights: on one GPU a smaller model of the same
+                    # architecture walks through the same code
+                    rep["model"] = stand_in
     common = {
         "concurrency": args.concurrency, "prompt_len": args.prompt_len, "decode_len": args.decode_len,
         "steps": args.steps, "warmup": args.warmup, "max_num_batched_tokens": args.max_num_batched_tokens,

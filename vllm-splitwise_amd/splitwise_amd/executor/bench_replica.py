@@ -222,17 +222,23 @@ def _run(spec: Dict[str, Any]) -> None:
         "kv_bytes_pushed": int(executor.kv_bytes_pushed()) if hasattr(executor, "kv_bytes_pushed") else 0,
         "kv_migration": None, "roofline": None,
     }
-    if on_gpu and spec["kind"] == "split":
-        result["kv_migration"] = _kv_push_bandwidth(executor, same_device)
-    if on_gpu and index == 0 and ctx_samples and not spec.get("no_roofline"):
-        if spec["kind"] == "split":
-            prof = executor.profile_token_pool("profile_decode_attention", samples=ctx_samples)
-            result["roofline"] = _roofline_from_profile(prof, "first token GPU of replica 0")
-        else:
-            prof = executor.driver_worker.profile_decode_attention(ctx_samples)
-            result["roofline"] = _roofline_from_profile(prof, "replica 0")
-    if on_gpu and spec["kind"] == "split":
-        executor.driver_worker.check_kv_status()
+    # the probes come after the measurement and must never cost it: a probe that fails is reported as such
+    try:
+        if on_gpu and spec["kind"] == "split":
+            result["kv_migration"] = _kv_push_bandwidth(executor, same_device)
+        if on_gpu and index == 0 and ctx_samples and not spec.get("no_roofline"):
+            if spec["kind"] == "split":
+                prof = executor.profile_token_pool("profile_decode_attention", samples=ctx_samples)
+                result["roofline"] = _roofline_from_profile(prof, "first token GPU of replica 0")
+            else:
+                prof = executor.driver_worker.profile_decode_attention(ctx_samples)
+                result["roofline"] = _roofline_from_profile(prof, "replica 0")
+        if on_gpu and spec["kind"] == "split":
+            executor.driver_worker.check_kv_status()
+    except Exception as exc:             # noqa: BLE001
+        import traceback
+        traceback.print_exc()
+        result["probe_error"] = f"{type(exc).__name__}: {exc}"[:400]
     try:
         executor.shutdown()
     except Exception:                    # noqa: BLE001  (the numbers are in hand; the processes die with this one)

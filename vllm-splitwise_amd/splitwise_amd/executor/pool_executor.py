@@ -275,6 +275,15 @@ class PoolExecutor(ExecutorBase):
             decode_out = outs[self.token_pool[0]]
         return prompt_out, decode_out
 
+    def profile_token_pool(self, name: str, lane: int = 0, **kwargs):
+        """Runs a measurement method of ``Worker`` on the first rank of the token pool (rank 0 when the pool is
+        co-located)."""
+        rank = self.token_pool[0]
+        if rank == 0:
+            return getattr(self.driver_worker, name)(**kwargs)
+        self._send(rank, name, kwargs)
+        return self._wait(rank)
+
     def kv_bytes_pushed(self) -> int:
         comm = self.driver_worker.kvcache_comm_manager
         return comm.kvcache_comm.bytes_pushed if comm and comm.kvcache_comm else 0
