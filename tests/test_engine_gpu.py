@@ -219,9 +219,15 @@ def test_padded_and_packed_prompt_layouts_agree():
     torch.cuda.empty_cache()
 
 
-@pytest.mark.parametrize("tp,split,eager", [(2, False, True), (2, False, False), (2, True, False), (4, True, False),
-                                            (4, True, True)])
-def test_tensor_parallel_pools_match_cpu_model(tp, split, eager, monkeypatch):
+@pytest.mark.parametrize("tp,split,eager,pipeline,token_pools", [
+    (2, False, True, False, 1), (2, False, False, False, 1), (2, True, False, False, 1), (4, True, False, False, 1),
+    (4, True, True, False, 1),
+    # pipelined steps: every pool keeps its next step queued; ranks that do not sample read their next input
+    # tokens from ids that their pool's first rank sampled and sent them device to device
+    (2, False, False, True, 1), (2, True, False, True, 1), (4, True, False, True, 1),
+    # one prompt pool of two ranks feeding two token pools of two ranks (six processes), staged prompt cache
+    (2, True, False, True, 2)])
+def test_tensor_parallel_pools_match_cpu_model(tp, split, eager, pipeline, token_pools, monkeypatch):
     """Tensor-parallel ranks per pool (co-located, then a prompt pool pushing its KV shards to a token
     pool: up to eight worker processes -- two pools of four, the 70B configuration in miniature, with
     the two KV heads replicated over the four ranks), all on this one GPU with gloo standing in for
@@ -234,10 +240,14 @@ def test_tensor_parallel_pools_match_cpu_model(tp, split, eager, monkeypatch):
     monkeypatch.setenv("SPLITWISE_TP_BACKEND", "gloo")
     random.seed(3)
     llm = LLM("llama-tiny", tensor_parallel_size=tp, sep_prompt_token=split, num_gpu_blocks_override=128,
-              max_num_seqs=8, max_model_len=512, swap_space=0.01, enforce_eager=eager)
+              max_num_seqs=8, max_model_len=512, swap_space=0.01, enforce_eager=eager, pipeline_steps=pipeline,
+              token_pools=token_pools, max_num_batched_tokens=512)
     from splitwise_amd.model_executor import custom_all_reduce
     assert custom_all_reduce.is_initialized()          # the pools' all-reduces run as direct peer reads
     ex = llm.llm_engine.model_executor
+    assert llm.llm_engine.pipeline_split == (pipeline and split)
+    assert llm.llm_engine.pipeline_steps == (pipeline and not split)
+    assert len(llm.llm_engine.schedulers) == token_pools
     decode_rank = tp if split else 0
     graphs = ex._call_all([decode_rank], "num_captured_graphs")[decode_rank]
     assert (graphs == 0) == eager, graphs

@@ -15,29 +15,40 @@ import pytest
 import conftest  # noqa: F401  (adds the package and the repo root to sys.path)
 
 
-def _engine(tp: int, tmp: str, blocks: int = 64):
+def _engine(tp: int, tmp: str, blocks: int = 64, pipeline: bool = False, token_pools: int = 1, staged: bool = False):
     from split_fakes import FakeWorker
     from splitwise_amd import EngineArgs, LLMEngine
     from splitwise_amd.executor.pool_executor import PoolExecutor
     os.environ["SPLIT_FAKE_DIR"] = tmp
     os.environ["SPLIT_FAKE_BLOCKS"] = str(blocks)
     args = EngineArgs(model="llama-tiny", sep_prompt_token=True, tensor_parallel_size=tp, max_num_seqs=6,
-                      max_model_len=128, max_num_batched_tokens=512, swap_space=0.001)
+                      max_model_len=128, max_num_batched_tokens=512, swap_space=0.001, pipeline_steps=pipeline,
+                      token_pools=token_pools, staged_prompt_cache=staged)
     mc, cc, pc, sc, dc = args.create_engine_configs()
-    assert pc.world_size == 2 * tp and pc.num_prompt_workers == tp
-    executor = PoolExecutor(mc, cc, pc, sc, dc, worker_cls=FakeWorker, devices=[0] * (2 * tp))
+    assert pc.world_size == (1 + token_pools) * tp and pc.num_prompt_workers == tp
+    executor = PoolExecutor(mc, cc, pc, sc, dc, worker_cls=FakeWorker, devices=[0] * pc.world_size)
     return LLMEngine(mc, cc, pc, sc, dc, executor=executor), executor, cc
 
 
-@pytest.mark.parametrize("tp", [2, 4])
-def test_split_pools_of_tensor_parallel_ranks(tp):
+@pytest.mark.parametrize("tp,pipeline,token_pools,staged", [(2, False, 1, False), (4, False, 1, False),
+                                                            (2, True, 1, False), (2, True, 1, True), (2, True, 2, True)])
+def test_split_pools_of_tensor_parallel_ranks(tp, pipeline, token_pools, staged):
+    """Lock-stepped pools as in the reference's world; pipelined pools (each pool keeps a step queued: the token
+    pool's ranks read their next input tokens from ids their first rank sampled); a prompt pool whose cache holds
+    only the prompts in flight; and one prompt pool of two ranks feeding two token pools of two ranks (six
+    processes), prompt rank i pushing to rank i of the pool a sequence decodes on."""
     from split_fakes import VOCAB, next_token
     from splitwise_amd import SamplingParams
     with tempfile.TemporaryDirectory() as tmp:
-        engine, executor, cc = _engine(tp, tmp)
+        engine, executor, cc = _engine(tp, tmp, 96 if staged else 64, pipeline, token_pools, staged)
         try:
-            assert cc.num_gpu_blocks == 64                      # the smallest over all ranks (token ranks offer 80)
+            assert engine.pipeline_split == pipeline and len(engine.schedulers) == token_pools
+            if staged:
+                assert cc.num_gpu_blocks == 96 + 16 and executor.prompt_cache_blocks == 76
+            else:
+                assert cc.num_gpu_blocks == 64                  # the smallest over all ranks (token ranks offer 80)
             assert executor.prompt_pool == list(range(tp)) and executor.token_pool == list(range(tp, 2 * tp))
+            assert executor.token_pools[-1] == list(range(token_pools * tp, (token_pools + 1) * tp))
             rng = random.Random(1)
             prompts = {str(i): [rng.randrange(VOCAB) for _ in range(rng.choice([1, 5, 16, 17, 40]))] for i in range(10)}
             lens = {rid: rng.choice([1, 2, 9, 20]) for rid in prompts}
@@ -58,6 +69,49 @@ def test_split_pools_of_tensor_parallel_ranks(tp):
                     seq.append(next_token(seq))
                 assert finished[rid] == seq[len(prompt):], rid
             assert executor.kv_bytes_pushed() > 0
+            for sched in engine.schedulers:
+                assert sched.block_manager.gpu_allocator._next_fresh > 0          # every pool served requests
+                assert sched.block_manager.get_num_free_gpu_blocks() == cc.num_gpu_blocks
+        finally:
+            executor.shutdown()
+
+
+def test_a_colocated_tensor_parallel_pool_runs_pipelined_steps():
+    """tensor_parallel_size=2 without split pools, pipeline_steps: step n + 1 is launched on both ranks before
+    step n's tokens are known on the host; the second rank never samples and reads its next input tokens from
+    what the first rank sampled."""
+    from split_fakes import VOCAB, FakeWorker, next_token
+    from splitwise_amd import EngineArgs, LLMEngine, SamplingParams
+    from splitwise_amd.executor.pool_executor import PoolExecutor
+    with tempfile.TemporaryDirectory() as tmp:
+        os.environ["SPLIT_FAKE_DIR"] = tmp
+        os.environ["SPLIT_FAKE_BLOCKS"] = "64"
+        args = EngineArgs(model="llama-tiny", tensor_parallel_size=2, max_num_seqs=6, max_model_len=128,
+                          max_num_batched_tokens=512, swap_space=0.001, pipeline_steps=True)
+        mc, cc, pc, sc, dc = args.create_engine_configs()
+        executor = PoolExecutor(mc, cc, pc, sc, dc, worker_cls=FakeWorker, devices=[0, 0])
+        try:
+            engine = LLMEngine(mc, cc, pc, sc, dc, executor=executor)
+            assert engine.pipeline_steps and not engine.pipeline_split
+            rng = random.Random(4)
+            prompts = {str(i): [rng.randrange(VOCAB) for _ in range(rng.choice([1, 5, 16, 17, 40]))] for i in range(8)}
+            lens = {rid: rng.choice([1, 2, 9, 20]) for rid in prompts}
+            pending, finished, steps = list(prompts), {}, 0
+            while pending or engine.has_unfinished_requests():
+                if pending and steps % 2 == 0:
+                    rid = pending.pop(0)
+                    engine.add_request(rid, None, SamplingParams(temperature=0.0, max_tokens=lens[rid], ignore_eos=True),
+                                       prompt_token_ids=prompts[rid])
+                for out in engine.step():
+                    if out.finished:
+                        finished[out.request_id] = list(out.outputs[0].token_ids)
+                steps += 1
+                assert steps < 2000
+            for rid, prompt in prompts.items():
+                seq = list(prompt)
+                for _ in range(lens[rid]):
+                    seq.append(next_token(seq))
+                assert finished[rid] == seq[len(prompt):], rid
         finally:
             executor.shutdown()
 

@@ -7,13 +7,21 @@ cache to rank i+tp.  One process per GPU: rank 0 lives in the engine process, ev
 a child process running the worker command loop; TP collectives are RCCL's (torch.distributed
 "nccl") inside each pool.
 
-Differences from the reference, both deliberate:
+Differences from the reference, all deliberate:
   * no Ray and no per-step tensor broadcast: every rank of a pool receives the same small step
     command (sequence metadata, block operations) over its control channel and prepares its own
     input tensors, so there is no driver-to-follower tensor traffic at all; only the first rank
     of a pool reports the sampled tokens;
-  * with split pools, ``execute_split`` runs a prompt step and a decode step at the same time.
+  * with split pools, ``execute_split`` runs a prompt step and a decode step at the same time;
+  * pipelined steps (``launch_prompt`` / ``decode_send`` / ``decode_collect``, and ``execute_model(defer=True)``
+    for a co-located pool): a pool always has its next step queued while the engine works on the last one's
+    tokens -- the reference waits for every rank's reply before it schedules again
+    (ray_gpu_executor.py:284-324, its TODO at :292-293).  The sampled ids reach the pool's other ranks device
+    to device (ModelRunner._share_sampled_ids);
+  * several token pools behind one prompt pool (``parallel_config.num_token_pools``), and a prompt pool
+    whose cache holds only the prompts in flight (``staged_prompt_cache``), as in SplitwiseExecutor.
 """
+import copy
 import os
 import time
 from typing import Any, Dict, List, Optional, Sequence, Tuple
@@ -45,6 +53,32 @@ def _listening_store(world_size: int):
     store = dist.TCPStore("127.0.0.1", 0, world_size, is_master=True, wait_for_workers=False,
                           timeout=datetime.timedelta(seconds=_control_timeout()))
     return store, store.port
+
+
+class _PoolPending:
+    """A pipelined prompt step of a tensor-parallel pool: the first rank's samples, finished when the other
+    ranks have acknowledged the step (which they do once their KV pushes have left) as well."""
+
+    def __init__(self, pending, executor: "PoolExecutor", followers: List[int]) -> None:
+        self.pending = pending
+        self.executor = executor
+        self.followers = followers
+
+    def done(self) -> bool:
+        if not self.pending.done():
+            return False
+        for r in self.followers:
+            self.executor._drain_acks(r)
+        return all(self.executor._unread_acks.get(r, 0) == 0 for r in self.followers)
+
+    def wait(self) -> None:
+        self.pending.wait()
+        for r in self.followers:
+            self.executor._await_acks(r)
+
+    def resolve(self):
+        self.wait()
+        return self.pending.resolve()
 
 
 class PoolExecutor(ExecutorBase):
@@ -91,7 +125,14 @@ class PoolExecutor(ExecutorBase):
                                         is_driver_worker=True, kv_transport_init=transport_init, **extra)
         self.all_ranks = list(range(self.world))
         self.prompt_pool = list(range(self.tp))
-        self.token_pool = list(range(self.tp, 2 * self.tp)) if self.split else self.prompt_pool
+        self.num_lanes = max(getattr(parallel_config, "num_token_pools", 1), 1) if self.split else 1
+        self.staged = bool(getattr(parallel_config, "staged_prompt_cache", False))
+        self.token_pools = ([list(range(self.tp * (1 + j), self.tp * (2 + j))) for j in range(self.num_lanes)]
+                            if self.split else [self.prompt_pool])
+        self.token_pool = self.token_pools[0]
+        self.supports_pipelined_split = self.split
+        self.supports_deferred_samples = not self.split
+        self._unread_acks: Dict[int, int] = {}
         try:
             self._call_all(self.all_ranks, "init_model")
             self._call_all(self.all_ranks, "load_model")
@@ -127,10 +168,11 @@ class PoolExecutor(ExecutorBase):
 
     # ------------------------------------------------------------ control plane
     def _send(self, rank: int, name: str, kwargs: dict) -> None:
-        if name == "execute_model":
+        if name in ("execute_model", "execute_deferred"):
             # decode commands travel without the sequences' token ids
             slim = slim_decode_metadata(kwargs["seq_group_metadata_list"])
-            self.channels[rank].send(("execute", dict(kwargs, seq_group_metadata_list=slim)))
+            tag = "execute" if name == "execute_model" else "execute_deferred"
+            self.channels[rank].send((tag, dict(kwargs, seq_group_metadata_list=slim)))
         else:
             self.channels[rank].send(("call", name, kwargs))
 
@@ -190,11 +232,14 @@ class PoolExecutor(ExecutorBase):
             results[r] = self._wait(r)
         return results
 
-    def _exchange(self, obj):
-        """One round of the KV-transport handshake: every worker hands in one object and gets its
-        pair's.  Runs inside the local prompt worker's set-up, which is when the others ask too."""
+    def _exchange(self, obj, lane: int = 0):
+        """One round of the KV-transport handshake with token pool ``lane``: every prompt rank and every rank of
+        that pool hands in one object and gets its pair's (prompt rank i <-> rank i of the pool).  Runs inside
+        the local prompt worker's set-up, which is when the others ask too; the prompt ranks go through the
+        pools in the same order as this one."""
         deadline = time.monotonic() + _control_timeout()
-        waiting = set(range(1, 2 * self.tp))
+        token = self.token_pools[lane]
+        waiting = set(self.prompt_pool[1:]) | set(token)
         handed_in: Dict[int, Any] = {}
         while waiting:                                      # in whatever order they arrive
             progressed = False
@@ -217,27 +262,51 @@ class PoolExecutor(ExecutorBase):
                 handed_in[r] = payload
                 waiting.discard(r)
         for i in range(1, self.tp):                         # pairs that live entirely in other processes
-            self.channels[i].send(("kv_exchange", handed_in[i + self.tp]))
-            self.channels[i + self.tp].send(("kv_exchange", handed_in[i]))
-        self.channels[self.tp].send(("kv_exchange", obj))   # the local worker's own pair
-        return handed_in[self.tp]
+            self.channels[i].send(("kv_exchange", handed_in[token[i]]))
+            self.channels[token[i]].send(("kv_exchange", handed_in[i]))
+        self.channels[token[0]].send(("kv_exchange", obj))  # the local worker's own pair
+        return handed_in[token[0]]
 
     # -------------------------------------------------------------------- cache
+    def _call_pools(self, name: str, prompt_kwargs: dict, token_kwargs: dict) -> None:
+        """``name`` on every rank, the prompt pool and the token pools with arguments of their own."""
+        if not self.split or prompt_kwargs is token_kwargs:
+            self._call_all(self.all_ranks, name, **token_kwargs)
+            return
+        token_ranks = [r for pool in self.token_pools for r in pool]
+        for r in token_ranks:
+            self._send(r, name, token_kwargs)
+        self._call_all(self.prompt_pool, name, **prompt_kwargs)
+        for r in token_ranks:
+            self._wait(r)
+
     def _init_cache(self, override: Optional[int]) -> None:
+        from .splitwise_executor import staged_prompt_blocks
         cc = self.cache_config
+        staging = staged_prompt_blocks(self.scheduler_config, cc.block_size) if self.staged else None
         if override is None:
             sizes = self._call_all(self.all_ranks, "profile_num_available_blocks", block_size=cc.block_size,
                                    gpu_memory_utilization=cc.gpu_memory_utilization,
                                    cpu_swap_space=cc.swap_space_bytes, cache_dtype=cc.cache_dtype)
-            # a block id means the same block on every rank: all caches get the smallest size
-            num_gpu_blocks = min(s[0] for s in sizes.values())
-            num_cpu_blocks = min(s[1] for s in sizes.values())
+            # a block id means the same block on every rank that shares a block space: all of them get the
+            # smallest size (a staged prompt pool has a block space of its own)
+            counted = [s for r, s in sizes.items() if not (self.staged and r in self.prompt_pool)]
+            num_gpu_blocks = min(s[0] for s in counted)
+            num_cpu_blocks = min(s[1] for s in counted)
+            if self.staged and min(sizes[r][0] for r in self.prompt_pool) < staging:
+                raise ValueError(f"a prompt GPU has room for {min(sizes[r][0] for r in self.prompt_pool)} cache "
+                                 f"blocks, a prompt step needs {staging}")
         else:
             per_block = self.driver_worker.get_cache_block_size_bytes(cc.block_size, cc.cache_dtype)
             num_gpu_blocks, num_cpu_blocks = override, int(cc.swap_space_bytes // per_block)
         check_block_budget(self.model_config.max_model_len, cc.block_size, num_gpu_blocks)
         cc.num_gpu_blocks, cc.num_cpu_blocks = num_gpu_blocks, num_cpu_blocks
-        self._call_all(self.all_ranks, "init_cache_engine", cache_config=cc)
+        prompt_cc = cc
+        if self.staged:
+            prompt_cc = copy.copy(cc)
+            prompt_cc.num_gpu_blocks, prompt_cc.num_cpu_blocks = staging, 0
+        self.prompt_cache_blocks = prompt_cc.num_gpu_blocks
+        self._call_pools("init_cache_engine", dict(cache_config=prompt_cc), dict(cache_config=cc))
         self._call_all(self.all_ranks, "warm_up_model")
         if self.split:
             self._call_all(self.all_ranks, "setup_kvcache_comm")
@@ -252,11 +321,15 @@ class PoolExecutor(ExecutorBase):
                       blocks_to_swap_in: Dict[int, int], blocks_to_swap_out: Dict[int, int],
                       blocks_to_copy: Dict[int, List[int]],
                       blocks_to_nw: Optional[Dict[int, List[Tuple[int, int]]]] = None,
-                      nw_epochs: Optional[Dict[int, int]] = None) -> SamplerOutput:
+                      nw_epochs: Optional[Dict[int, int]] = None, defer: bool = False) -> SamplerOutput:
         if not seq_group_metadata_list:
             return SamplerOutput([])
         kwargs = self._kwargs(seq_group_metadata_list, blocks_to_swap_in, blocks_to_swap_out, blocks_to_copy,
                               blocks_to_nw, nw_epochs)
+        if defer:
+            return self.execute_deferred(kwargs)
+        for r in self.prompt_pool[1:]:
+            self._await_acks(r)
         pool = self.prompt_pool if seq_group_metadata_list[0].is_prompt else self.token_pool
         return self._call_all(pool, "execute_model", **kwargs)[pool[0]]
 
@@ -274,6 +347,57 @@ class PoolExecutor(ExecutorBase):
             outs = {r: self._wait(r) for r in self.token_pool}
             decode_out = outs[self.token_pool[0]]
         return prompt_out, decode_out
+
+    # ------------------------------------------------------------ pipelined steps
+    def _drain_acks(self, rank: int) -> None:
+        """Reads the acknowledgements a rank has sent for commands whose result nobody waits for (a follower's
+        deferred steps).  An error among them is raised here, one command late."""
+        ch = self.channels[rank]
+        while self._unread_acks.get(rank, 0) > 0 and ch.poll(0.0):
+            status, result = self._recv(rank, time.monotonic() + _control_timeout())
+            self._unread_acks[rank] -= 1
+            if status == "error":
+                raise RuntimeError(f"worker {rank} failed: {result}")
+
+    def _await_acks(self, rank: int) -> None:
+        while self._unread_acks.get(rank, 0) > 0:
+            status, result = self._recv(rank, time.monotonic() + _control_timeout())
+            self._unread_acks[rank] -= 1
+            if status == "error":
+                raise RuntimeError(f"worker {rank} failed: {result}")
+
+    def execute_deferred(self, kwargs: dict):
+        """A co-located pool's step with the samples left on the device: -> the first rank's PendingSamples.
+        The other ranks acknowledge when they have queued the step; nobody waits for that."""
+        for r in self.prompt_pool[1:]:
+            self._drain_acks(r)
+            self._send(r, "execute_deferred", kwargs)
+            self._unread_acks[r] = self._unread_acks.get(r, 0) + 1
+        return self.driver_worker.execute_model(**kwargs, defer=True)
+
+    def launch_prompt(self, prompt_kwargs: dict, lane: int = 0):
+        """Starts a prompt step on the prompt pool whose sequences will decode on token pool ``lane``;
+        -> an object with done() / wait() / resolve() like the first rank's PendingSamples.  The step counts as
+        finished when every rank of the pool has pushed its shard of the KV cache."""
+        followers = self.prompt_pool[1:]
+        kwargs = dict(prompt_kwargs, nw_peer=lane) if lane else prompt_kwargs
+        for r in followers:
+            self._drain_acks(r)
+            self._send(r, "execute_model", kwargs)          # replies once its pushes have left (Worker.execute_model)
+            self._unread_acks[r] = self._unread_acks.get(r, 0) + 1
+        pending = self.driver_worker.execute_model(**kwargs, defer=True)
+        return _PoolPending(pending, self, followers)
+
+    def decode_send(self, decode_kwargs: Optional[dict], lane: int = 0) -> None:
+        for r in self.token_pools[lane]:
+            if decode_kwargs is not None:
+                self._send(r, "execute_deferred", decode_kwargs)
+            else:
+                self.channels[r].send(("flush",))
+
+    def decode_collect(self, lane: int = 0) -> Optional[SamplerOutput]:
+        outs = [self._wait(r) for r in self.token_pools[lane]]
+        return outs[0]
 
     def profile_token_pool(self, name: str, lane: int = 0, **kwargs):
         """Runs a measurement method of ``Worker`` on the first rank of the token pool (rank 0 when the pool is

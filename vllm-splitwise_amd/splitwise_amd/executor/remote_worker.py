@@ -13,7 +13,9 @@ from ..worker.worker import Worker
 
 def make_exchange(channel):
     """Symmetric swap with the paired worker over the control channel."""
-    def exchange(obj):
+    def exchange(obj, peer_index: int = 0):
+        # (a prompt worker with several token pools swaps with them in turn; the other end of the channel
+        # knows the order, so the index does not travel)
         channel.send(("kv_exchange", obj))
         tag, peer = channel.recv()
         assert tag == "kv_exchange", tag
@@ -67,7 +69,7 @@ def worker_loop(channel, cfg: Dict[str, Any], worker_cls=Worker) -> None:
                     # launch the new step first, then report the PREVIOUS one: the device always has
                     # the next step queued while the engine works on the last one's tokens
                     new = worker.execute_model(**args[0], defer=True) if cmd == "execute_deferred" else None
-                    prev, pending = pending, new
+                    prev, pending = pending, (new if reports else None)
                     if prev is None:
                         channel.send(("ok", None))
                     else:

@@ -120,6 +120,37 @@ class PendingSamples:
         self._report_order = positions
 
 
+class FollowerSamples:
+    """What a tensor-parallel rank that does not sample keeps of a pipelined step: the sampled token ids, received
+    from its pool's first rank on the device, so that the next decode step can read its input tokens from them
+    exactly as the first rank does from its ``PendingSamples``.  Nothing to report."""
+
+    def __init__(self, seq_groups, next_ids: torch.Tensor) -> None:
+        self.seq_groups = seq_groups
+        self.next_ids = next_ids
+        self.row_of: Dict[int, int] = {}
+        for seq_ids, _ in seq_groups:
+            for seq_id in seq_ids:
+                self.row_of[seq_id] = len(self.row_of)
+        self.after_sync = []
+        self.extra_events = []
+
+    def done(self) -> bool:
+        return True
+
+    def wait(self) -> None:
+        pass
+
+    def resolve(self) -> None:
+        checks, self.after_sync = self.after_sync, []
+        for check in checks:
+            check()
+        return None
+
+    def reorder(self, positions: List[int]) -> None:
+        pass                         # rows stay in the order the step ran in, which is what the next step looks up
+
+
 class Sampler(nn.Module):
     def __init__(self, vocab_size: int, org_vocab_size: Optional[int] = None) -> None:
         super().__init__()

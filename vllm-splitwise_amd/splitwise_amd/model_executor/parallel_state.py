@@ -121,3 +121,18 @@ def tensor_model_parallel_gather(x: torch.Tensor, dst: int = 0, dim: int = -1):
     parts = [torch.empty_like(x) for _ in range(_TP_WORLD)] if _TP_RANK == dst else None
     dist.gather(x.contiguous(), parts, dst=dist.get_global_rank(_TP_GROUP, dst), group=_TP_GROUP)
     return torch.cat(parts, dim=dim) if _TP_RANK == dst else None
+
+
+def tensor_model_parallel_broadcast_from_first(x: torch.Tensor) -> torch.Tensor:
+    """``x`` of the tensor-parallel group's first rank, on every rank of the group, in place (the other ranks
+    pass a tensor of the same shape and dtype to receive into).  Stream-ordered: the host does not wait."""
+    if _TP_WORLD == 1:
+        return x
+    src = dist.get_global_rank(_TP_GROUP, 0)
+    if _HOST_STAGED and x.is_cuda:
+        host = x.cpu()
+        dist.broadcast(host, src=src, group=_TP_GROUP)
+        x.copy_(host)
+        return x
+    dist.broadcast(x, src=src, group=_TP_GROUP)
+    return x

@@ -25,7 +25,7 @@ import torch
 
 from ..config import DeviceConfig, ModelConfig, ParallelConfig, SchedulerConfig
 from ..model_executor.input_metadata import InputMetadata
-from ..model_executor.layers.sampler import PendingSamples, SamplingMetadata
+from ..model_executor.layers.sampler import FollowerSamples, PendingSamples, SamplingMetadata
 from ..model_executor.model_loader import get_model
 from ..sampling_params import SamplingParams
 from ..sequence import PLACEHOLDER_TOKEN_ID, SamplerOutput, SequenceData, SequenceGroupMetadata
@@ -321,10 +321,28 @@ class ModelRunner:
             hidden = self.model(tokens.view(-1), positions.view(-1), kv_caches, md)
         sampling_md.defer = defer
         result = self.model.sample(hidden, sampling_md)
+        if defer and self.parallel_config is not None and self.parallel_config.tensor_parallel_size > 1:
+            result = self._share_sampled_ids(result, sampling_md)
         if not is_prompt and restore is not None and result is not None:
             result.reorder(restore[1])           # report in the order the step was asked for
         self.pending = result if defer else None
         return result
+
+    def _share_sampled_ids(self, result, sampling_md: SamplingMetadata):
+        """Pipelined steps of a tensor-parallel pool: only the pool's first rank samples (the logits are gathered
+        there), but every rank's NEXT decode step reads its input tokens from the device.  The first rank sends
+        the sampled ids to the others, device to device; they keep them as ``FollowerSamples``."""
+        from ..model_executor.parallel_state import tensor_model_parallel_broadcast_from_first
+        rows = sampling_md.selected_token_indices.numel()
+        if result is not None:
+            ids = result.next_ids
+            if ids.dtype != torch.long or not ids.is_contiguous():
+                ids = ids.to(torch.long).contiguous()
+            tensor_model_parallel_broadcast_from_first(ids)
+            return result
+        ids = torch.empty(rows, dtype=torch.long, device=self.device)
+        tensor_model_parallel_broadcast_from_first(ids)
+        return FollowerSamples(sampling_md.seq_groups, ids)
 
     def _decode_rule(self, num_seqs: int, max_ctx: int, mean_ctx: Optional[float]) -> bool:
         """PagedAttentionImpl.use_v1 for this model's attention geometry."""

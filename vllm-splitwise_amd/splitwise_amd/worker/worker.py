@@ -238,8 +238,8 @@ class Worker:
         # a bounded wait that gave up (hand-off signal, all-reduce barrier) lets the stream run on over
         # data that never arrived: look at the status words once the step has finished and fail loudly
         # (the reference's proxy_channel.wait(1e8) traps, its all-reduce barrier hangs)
-        if defer and hasattr(output, "after_sync"):
-            output.after_sync.append(self.check_step_status)
+        if defer and hasattr(output, "after_sync") and hasattr(output, "event"):
+            output.after_sync.append(self.check_step_status)        # looked at when the step's samples are collected
         else:
             self.check_step_status()
         return output
