@@ -291,9 +291,12 @@ class ModelRunner:
     # --------------------------------------------------------------- execution
     @torch.inference_mode()
     def execute_model(self, metas: List[SequenceGroupMetadata], kv_caches, blocks_to_nw=None,
-                      prompt_layout: str = "packed", defer: bool = False, nw_peer: int = 0):
+                      prompt_layout: str = "packed", defer: bool = False, nw_peer: int = 0,
+                      share_samples: Optional[bool] = None):
         """``defer``: return the step's ``PendingSamples`` (tokens still on the device) instead of a
-        ``SamplerOutput``; the next decode step takes unknown last tokens from it."""
+        ``SamplerOutput``; the next decode step takes unknown last tokens from it.  ``share_samples``
+        (tensor-parallel pools; default: whenever ``defer``): send the sampled ids to the pool's other ranks,
+        which must all make this call the same way -- off for a prompt pool, whose ranks never decode."""
         is_prompt = metas[0].is_prompt
         restore = None
         if is_prompt:
@@ -321,7 +324,9 @@ class ModelRunner:
             hidden = self.model(tokens.view(-1), positions.view(-1), kv_caches, md)
         sampling_md.defer = defer
         result = self.model.sample(hidden, sampling_md)
-        if defer and self.parallel_config is not None and self.parallel_config.tensor_parallel_size > 1:
+        if share_samples is None:
+            share_samples = defer
+        if share_samples and self.parallel_config is not None and self.parallel_config.tensor_parallel_size > 1:
             result = self._share_sampled_ids(result, sampling_md)
         if not is_prompt and restore is not None and result is not None:
             result.reorder(restore[1])           # report in the order the step was asked for

@@ -220,7 +220,8 @@ class Worker:
             for sem_id in blocks_to_nw:
                 comm.wait(sem_id, nw_epochs.get(sem_id))
         output = self.model_runner.execute_model(seq_group_metadata_list, self.gpu_cache, blocks_to_nw, defer=defer,
-                                                 nw_peer=nw_peer)
+                                                 nw_peer=nw_peer,
+                                                 share_samples=defer and not self.is_prompt_worker())
         if blocks_to_nw and comm is not None and self.is_prompt_worker() and is_prompt:
             for sem_id in blocks_to_nw:
                 if nw_peer:
