@@ -148,6 +148,36 @@ def test_large_launches_with_length_sorted_ragged_contexts(version, heads, num_s
     torch.testing.assert_close(out.cpu().float(), ref.float(), atol=atol, rtol=1e-5)
 
 
+@pytest.mark.parametrize("version", ["v1", "v2"])
+@pytest.mark.parametrize("heads", [(16, 16), (64, 8)])
+def test_bf16_queries_beyond_the_f16_range_over_an_fp8_cache(version, heads):
+    """bf16 activations over an e5m2 cache run their products in f16 on the matrix cores.  bf16 reaches 3e38,
+    f16 ends at 65504: queries of magnitude 1e5 (and 1e30) must give the scores the reference's fp32 products
+    give (fp8 widened to bf16, quant_utils.cuh:73-81; attention_utils.cuh:29-46), not infinities.  Only some
+    heads are large, so a per-head rescaling is exercised next to untouched heads."""
+    random.seed(5)
+    torch.manual_seed(5)
+    h, kvh = heads
+    dtype, head_size, block_size, nb, num_seqs = torch.bfloat16, 128, 16, 512, 6
+    scale = float(head_size ** -0.5)
+    query = torch.empty(num_seqs, h, head_size, dtype=dtype).uniform_(-scale, scale)
+    query[:, 1::3] *= 1.2e6                    # |q| up to 1e5: beyond f16
+    query[:, 2::5] *= 1e31                     # far beyond
+    query[0, 0, :] = 0.0                       # and an all-zero head
+    lens = [1, 17, 300, 700, 64, 513]
+    max_blocks = (max(lens) + block_size - 1) // block_size
+    block_tables = torch.tensor([[random.randint(0, nb - 1) for _ in range(max_blocks)] for _ in range(num_seqs)],
+                                dtype=torch.int)
+    context_lens = torch.tensor(lens, dtype=torch.int)
+    kc, vc = make_kv_caches(nb, block_size, kvh, head_size, dtype, cache_dtype="fp8_e5m2")
+    ref = oattn.paged_attention(query, kc, vc, block_tables, context_lens, scale, None)
+    assert torch.isfinite(ref.float()).all()
+    out = run_kernel(version, query.cuda(), kc.cuda(), vc.cuda(), kvh, scale, block_tables.cuda(),
+                     context_lens.cuda(), block_size, None, "fp8_e5m2")
+    assert torch.isfinite(out.float()).all()
+    torch.testing.assert_close(out.cpu().float(), ref.float(), atol=1e-2, rtol=1e-5)
+
+
 def test_strided_query_and_nan_tail():
     """The query is a slice of a fused qkv tensor (q_stride != H*D), and the unused tail of
     the last block holds NaNs that must not leak (attention_kernels.cu:342-351)."""

@@ -20,7 +20,10 @@
 // An fp8 (e5m2) cache is widened to f16 by a byte move (e5m2 is the high byte of a half) and the
 // products run as f16 whatever the activation dtype: bf16 queries and probabilities are re-expressed
 // in f16 (exact except below 2^-14, where the f16 step of 6e-8 is far below the 1e-2 tolerance of
-// the fp8 path).
+// the fp8 path).  bf16 reaches 3e38 where f16 ends at 65504: a head whose largest |q| exceeds 2^15 is
+// scaled down by a power of two first (exact) and the power goes into that head's softmax scale, so
+// large queries give the scores the reference's fp32 products give
+// (csrc/quantization/fp8_e5m2_kvcache/quant_utils.cuh:73-81 widens fp8 to bf16 and multiplies in fp32).
 #pragma once
 
 namespace sw {
@@ -124,19 +127,38 @@ paged_attention_mfma_kernel(void* __restrict__ out_, float* __restrict__ exp_sum
 
   // ---- Q^T fragments: lane (head r, dims 32 ks + 8 kq ..+7); zero for the unused head columns
   pa_u32x4 qf[KS];
+  float head_scale = scale;                // softmax scale of the lane's head column
   {
     const S* q = reinterpret_cast<const S*>(q_) + seq * q_stride + (int64_t)(head0 + r) * HEAD + 8 * kq;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       pa_u32x4 v = {0u, 0u, 0u, 0u};
       if (r < qg) v = *reinterpret_cast<const pa_u32x4*>(q + 32 * ks);
-      if constexpr (REEXPRESS) {
+      qf[ks] = v;
+    }
+    if constexpr (REEXPRESS) {
+      float amax = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
         for (int w = 0; w < 4; ++w)
-          v[w] = PaMfma<true>::pack(bf16_bits_to_float((uint16_t)(v[w] & 0xffffu)),
-                                    bf16_bits_to_float((uint16_t)(v[w] >> 16)));
+          amax = fmaxf(amax, fmaxf(fabsf(bf16_bits_to_float((uint16_t)(qf[ks][w] & 0xffffu))),
+                                   fabsf(bf16_bits_to_float((uint16_t)(qf[ks][w] >> 16)))));
+      amax = fmaxf(amax, __shfl_xor(amax, 16, 64));          // the four lanes of a head column hold its HEAD dims
+      amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
+      float down = 1.f;
+      if (amax > 32768.f && amax < INFINITY) {
+        int e;
+        (void)frexpf(amax, &e);                               // amax = m * 2^e, 0.5 <= m < 1
+        down = ldexpf(1.f, 15 - e);                           // |q| * down <= 2^15
+        head_scale = scale * ldexpf(1.f, e - 15);
       }
-      qf[ks] = v;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int w = 0; w < 4; ++w)
+          qf[ks][w] = PaMfma<true>::pack(bf16_bits_to_float((uint16_t)(qf[ks][w] & 0xffffu)) * down,
+                                         bf16_bits_to_float((uint16_t)(qf[ks][w] >> 16)) * down);
     }
   }
   const float slope = (alibi_slopes && r < qg) ? alibi_slopes[head0 + r] : 0.f;
@@ -222,7 +244,7 @@ paged_attention_mfma_kernel(void* __restrict__ out_, float* __restrict__ exp_sum
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int token = g_tok0 + 16 * t + 4 * kq + i;
-        float x = s[t][i] * scale;
+        float x = s[t][i] * head_scale;
         x += (slope != 0.f) ? slope * (float)(token - ctx + 1) : 0.f;
         x = token < tok_end ? x : -FLT_MAX;
         s[t][i] = x;
