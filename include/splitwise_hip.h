@@ -49,8 +49,10 @@ const char* sw_last_error(void);
  * 4: sw_kv_push takes max_workgroups.
  * 5: sw_rotary_embedding_and_cache added; the all-reduce signal area (sw_custom_ar_signal_bytes)
  *    grew from 2304 to 2560 bytes, which moves the status word at its end.
- * 6: sw_kv_push_mapped added. */
-#define SW_ABI_VERSION 6
+ * 6: sw_kv_push_mapped added.
+ * 7: sw_context_attention_split, sw_context_attention_split_parts, sw_context_attention_split_workspace_bytes
+ *    added. */
+#define SW_ABI_VERSION 7
 int sw_abi_version(void);
 
 /* csrc/cuda_utils_kernels.cu:16-35 get_max_shared_memory_per_block_device_attribute:
@@ -354,6 +356,33 @@ int sw_context_attention(void* out, const void* query, const void* key, const vo
                          const float* alibi_slopes, int64_t q_stride, int64_t k_stride, int64_t v_stride,
                          int64_t out_stride, int64_t kv_block_stride, int64_t kv_head_stride,
                          int sliding_window, int act_dtype, void* stream);
+
+/* sw_context_attention with the key stages of every (query tile, sequence, head) -- the cached context, then the
+ * new tokens -- dealt out to num_parts workgroups, whose partial results (fp32, in `workspace`) a second kernel
+ * joins.  For launches that leave compute units idle otherwise: few new tokens over a long cached context (the
+ * chunks of a chunked prefill, a short question after a long shared prefix).  The reference's Triton kernel walks
+ * the whole context in one program per (sequence, head, 128-row block) (ops/prefix_prefill.py:621-745).
+ *   total_rows   rows of query / key / value / out (the partial results are indexed by row)
+ *   num_parts    1 = sw_context_attention; sw_context_attention_split_parts suggests a value from the launch's
+ *                shape and the longest possible context (max_context_len, e.g. max_blocks_per_seq * block_size)
+ *   workspace    at least sw_context_attention_split_workspace_bytes(...) bytes, 16-byte aligned; contents
+ *                need not be initialised; calls that share it must be ordered on one stream
+ * Head sizes that are multiples of 32 and block sizes that are multiples of 8 only (SW_ERR_INVALID otherwise;
+ * sw_context_attention_split_parts returns 1 for the others).  Results agree with sw_context_attention's within
+ * the rounding of one more fp32 summation.                                                             */
+int64_t sw_context_attention_split_workspace_bytes(int num_parts, int64_t total_rows, int num_heads,
+                                                   int head_size);
+int sw_context_attention_split_parts(int num_seqs, int max_new_len, int num_heads, int head_size,
+                                     int block_size, int max_context_len);
+int sw_context_attention_split(void* out, const void* query, const void* key, const void* value,
+                               const void* key_cache, const void* value_cache, const int32_t* block_tables,
+                               int max_blocks_per_seq, const int32_t* seq_starts, const int32_t* new_lens,
+                               const int32_t* ctx_lens, int num_seqs, int max_new_len, int num_heads,
+                               int num_kv_heads, int head_size, int block_size, float scale,
+                               const float* alibi_slopes, int64_t q_stride, int64_t k_stride, int64_t v_stride,
+                               int64_t out_stride, int64_t kv_block_stride, int64_t kv_head_stride,
+                               int sliding_window, int act_dtype, int64_t total_rows, int num_parts,
+                               void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------- all-reduce by direct peer reads
  * Replaces csrc/custom_all_reduce.cu:12-148 / custom_all_reduce.cuh:341-548 (init_custom_ar,

@@ -37,7 +37,7 @@ def _case(num_heads, num_queries_per_kv, head_size, dtype, block_size, new_lens,
     return q, k, v, k_cache, v_cache, table
 
 
-def _run(q, k, v, k_cache, v_cache, table, new_lens, ctx_lens, alibi=None, window=None):
+def _run(q, k, v, k_cache, v_cache, table, new_lens, ctx_lens, alibi=None, window=None, num_parts=1):
     from splitwise_amd import _C
     starts, acc = [], 0
     for n in new_lens:
@@ -50,7 +50,7 @@ def _run(q, k, v, k_cache, v_cache, table, new_lens, ctx_lens, alibi=None, windo
                                  torch.tensor(starts, dtype=torch.long, device=dev),
                                  torch.tensor(seq_lens, dtype=torch.long, device=dev),
                                  torch.tensor(ctx_lens, dtype=torch.long, device=dev), max(new_lens),
-                                 alibi.to(dev) if alibi is not None else None, window)
+                                 alibi.to(dev) if alibi is not None else None, window, num_parts)
     torch.cuda.synchronize()
     return out.cpu()
 
@@ -172,3 +172,56 @@ def test_seeded_random_launches_over_a_cached_prefix(seed):
     ref = oattn.context_attention(q, k, v, kc, vc, table, new_lens, ctx_lens, alibi, window)
     assert not torch.isnan(out.float()).any()
     torch.testing.assert_close(out.float(), ref.float(), atol=1e-3, rtol=1e-2)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_split_form_agrees_with_the_oracle(seed):
+    """The key stages of every (query tile, sequence, head) dealt out to 2-8 workgroups and joined by the reduce
+    kernel: random launches as above (parts that get no stage at all, parts that hold only context, only new
+    tokens, or the boundary between the two), ALiBi or a window, against the oracle and against the unsplit form."""
+    rng = random.Random(900 + seed)
+    dtype = rng.choice([torch.float16, torch.bfloat16])
+    head = rng.choice([64, 128, 128])
+    block_size = rng.choice([8, 16, 32])
+    per_kv = rng.choice([1, 2, 4])
+    heads = per_kv * rng.choice([1, 2, 3])
+    n = rng.randint(1, 4)
+    new_lens = [rng.choice([1, 31, 64, 65, 128, 129, 257]) if rng.random() < 0.5 else rng.randint(1, 300) for _ in range(n)]
+    ctx_lens = [rng.choice([0, 1, 63, 64, 65, 511]) if rng.random() < 0.4 else rng.randint(0, 1500) for _ in range(n)]
+    variant = rng.choice(["plain", "plain", "alibi", "window"])
+    parts = rng.choice([2, 3, 5, 8])
+    s = head ** -0.5
+    q, k, v, kc, vc, table = _case(heads, per_kv, head, dtype, block_size, new_lens, ctx_lens, scale_inputs=s,
+                                   seed=400 + seed)
+    alibi = torch.randn(heads, dtype=torch.float) * 0.05 if variant == "alibi" else None
+    window = rng.choice([40, 130, 700]) if variant == "window" else None
+    out = _run(q, k, v, kc, vc, table, new_lens, ctx_lens, alibi, window, num_parts=parts)
+    whole = _run(q, k, v, kc, vc, table, new_lens, ctx_lens, alibi, window, num_parts=1)
+    ref = oattn.context_attention(q, k, v, kc, vc, table, new_lens, ctx_lens, alibi, window)
+    assert not torch.isnan(out.float()).any()
+    torch.testing.assert_close(out.float(), ref.float(), atol=1e-3, rtol=1e-2)
+    torch.testing.assert_close(out.float(), whole.float(), atol=2e-4, rtol=1e-2)     # one more fp32 summation apart
+
+
+def test_split_form_is_chosen_for_few_new_tokens_over_a_long_context_and_refused_for_odd_shapes():
+    from splitwise_amd import _C
+    lib = _C.load_library()
+    # 512 new tokens on a 3584-token context, 32 heads: 128 workgroups -> 4 parts; a full launch is left alone
+    assert lib.sw_context_attention_split_parts(1, 512, 32, 128, 16, 3584) == 4
+    assert lib.sw_context_attention_split_parts(1, 64, 32, 128, 16, 8192) == 8
+    assert lib.sw_context_attention_split_parts(4, 512, 32, 128, 16, 3584) == 1
+    assert lib.sw_context_attention_split_parts(1, 512, 32, 128, 16, 512) == 1
+    assert lib.sw_context_attention_split_parts(1, 512, 32, 80, 16, 3584) == 1      # head sizes off multiples of 32
+    assert lib.sw_context_attention_split_parts(1, 512, 32, 128, 4, 3584) == 1      # no 8 consecutive keys per block
+    # the library's own choice (num_parts=None) on such a launch, against the oracle
+    dtype, head, bs = torch.bfloat16, 128, 16
+    new_lens, ctx_lens = [200], [1500]
+    q, k, v, kc, vc, table = _case(8, 2, head, dtype, bs, new_lens, ctx_lens, scale_inputs=head ** -0.5, seed=11)
+    assert lib.sw_context_attention_split_parts(1, 200, 8, head, bs, table.shape[1] * bs) > 1
+    out = _run(q, k, v, kc, vc, table, new_lens, ctx_lens, num_parts=None)
+    ref = oattn.context_attention(q, k, v, kc, vc, table, new_lens, ctx_lens)
+    torch.testing.assert_close(out.float(), ref.float(), atol=1e-3, rtol=1e-2)
+    # shapes the split form does not take are refused, not silently run unsplit
+    q, k, v, kc, vc, table = _case(4, 2, 80, dtype, 16, [40], [300], scale_inputs=80 ** -0.5, seed=12)
+    with pytest.raises(RuntimeError, match="cannot be split"):
+        _run(q, k, v, kc, vc, table, [40], [300], num_parts=2)

@@ -273,7 +273,7 @@ extern "C" {
 
 const char* sw_last_error(void) { return sw::g_last_error.c_str(); }
 
-int sw_abi_version(void) { return 6; }       // SW_ABI_VERSION of the header; tests/test_abi.py compares the two
+int sw_abi_version(void) { return 7; }       // SW_ABI_VERSION of the header; tests/test_abi.py compares the two
 
 int sw_get_max_shared_memory_per_block(int device, int* out_bytes) {
   SW_CHECK_ARG(out_bytes != nullptr, "out_bytes is NULL");

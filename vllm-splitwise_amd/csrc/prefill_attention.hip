@@ -88,6 +88,14 @@ struct PfContext {
   const int32_t* ctx_lens;        // [num_seqs]
   int max_blocks, block_size;
   int64_t k_block_stride, k_head_stride, v_block_stride, v_head_stride;   // elements
+  // Split form (num_parts > 1): the key stages of a (query tile, sequence, head) -- cached context first, then the
+  // new tokens -- are dealt out to num_parts workgroups (blockIdx.y); each leaves its unnormalised output, running
+  // maximum and sum per query row here, and context_attention_reduce_kernel joins them.
+  int num_parts;
+  float* part_o;                  // [num_parts, total_rows, num_heads, HEAD]
+  float* part_m;                  // [num_parts, total_rows, num_heads]   (log2 domain)
+  float* part_l;                  // [num_parts, total_rows, num_heads]
+  int64_t total_rows;
 };
 
 template <typename act_t, int HEAD, bool CTX, int WAVES>
@@ -277,6 +285,26 @@ prefill_attention_kernel(uint16_t* __restrict__ out, const uint16_t* __restrict_
   using One = std::integral_constant<int, 1>;
 
   using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
+  // the new tokens' key stages of this workgroup (phase 2), and the part of all stages that this workgroup takes
+  const int wg_end = q_end;
+  int wg_begin = 0;
+  if (sliding_window > 0) wg_begin = max(0, (q_base - sliding_window + 1) / kPfStage * kPfStage);
+  const int stages_all = (wg_end - wg_begin + kPfStage - 1) / kPfStage;
+  const int num_parts = CTX ? max(cx.num_parts, 1) : 1;
+  const int part = CTX ? (int)blockIdx.y : 0;
+  int t_lo = 0, t_hi = 0x7fffffff, s_lo = 0, s_hi = stages_all;
+  if (CTX && num_parts > 1) {                          // workgroup-uniform
+    const int ctx = cx.ctx_lens[seq];
+    int c0 = 0;
+    if (sliding_window > 0) c0 = max(0, (ctx + q_base - sliding_window + 1) / kPfStage * kPfStage);
+    const int cst = ctx > c0 ? (ctx - c0 + kPfStage - 1) / kPfStage : 0;
+    const int total = cst + stages_all;
+    const int g_lo = (int)((int64_t)total * part / num_parts), g_hi = (int)((int64_t)total * (part + 1) / num_parts);
+    t_lo = min(g_lo, cst);
+    t_hi = min(g_hi, cst);
+    s_lo = max(g_lo - cst, 0);
+    s_hi = max(g_hi - cst, 0);
+  }
   // The shared form of phase 1 needs 8 consecutive keys of a head element in one block and no pad rows in O^T
   const bool ctx_shared = CTX && DP == HEAD && cx.block_size % 8 == 0;
   if (CTX && ctx_shared) {
@@ -294,7 +322,9 @@ prefill_attention_kernel(uint16_t* __restrict__ out, const uint16_t* __restrict_
     const int q_abs = ctx + q_idx;
     int c0 = 0;
     if (sliding_window > 0) c0 = max(0, (ctx + q_base - sliding_window + 1) / kPfStage * kPfStage);
-    const int cstages = ctx > c0 ? (ctx - c0 + kPfStage - 1) / kPfStage : 0;       // workgroup-uniform
+    const int cstages_all = ctx > c0 ? (ctx - c0 + kPfStage - 1) / kPfStage : 0;   // workgroup-uniform
+    const int cfirst = c0 + t_lo * kPfStage;                                       // this workgroup's share of them
+    const int cstages = min(t_hi, cstages_all) - t_lo;
     u32x4 ckreg[LOADS], cvreg[LOADS];
     auto cfetch = [&](int k0) {
       static_for<LOADS>([&](auto IT) {
@@ -335,14 +365,14 @@ prefill_attention_kernel(uint16_t* __restrict__ out, const uint16_t* __restrict_
       });
     };
     if (cstages > 0) {
-      cfetch(c0);
+      cfetch(cfirst);
       ccommit(0);
-      if (cstages > 1) cfetch(c0 + kPfStage);
+      if (cstages > 1) cfetch(cfirst + kPfStage);
       __syncthreads();
     }
     int cbuf = 0;
     for (int t = 0; t < cstages; ++t) {                  // every wave meets every barrier
-      const int k0 = c0 + t * kPfStage;
+      const int k0 = cfirst + t * kPfStage;
       if (t + 1 < cstages) ccommit(cbuf ^ 1);
       if (t + 2 < cstages) cfetch(k0 + 2 * kPfStage);
       // (wave-uniform) this wave's window may begin after the stage
@@ -473,9 +503,6 @@ prefill_attention_kernel(uint16_t* __restrict__ out, const uint16_t* __restrict_
   const int k_end = min(q0 + kPfRows, q_end);        // this wave's keys: < k_end
   int k_begin = 0;
   if (sliding_window > 0) k_begin = max(0, (q0 - sliding_window + 1) / kPfKeys * kPfKeys);
-  const int wg_end = q_end;
-  int wg_begin = 0;
-  if (sliding_window > 0) wg_begin = max(0, (q_base - sliding_window + 1) / kPfStage * kPfStage);
 
   // (native vectors: arrays of HIP's uint4 struct, assigned under a condition, are kept in scratch
   //  memory by the compiler)
@@ -525,16 +552,19 @@ prefill_attention_kernel(uint16_t* __restrict__ out, const uint16_t* __restrict_
   //   iteration t:  stage t+1 registers -> LDS (the buffer that iteration t-1 read, released by its
   //                 barrier) | stage t+2 global -> registers | both score tiles of stage t: S = K . Q^T,
   //                 mask, one softmax update, O += V^T . P^T | barrier
-  const int stages = (wg_end - wg_begin + kPfStage - 1) / kPfStage;
+  const int stages = s_hi - s_lo;                      // all of them unless the stages are split over workgroups
+  const int wg_first = wg_begin + s_lo * kPfStage;
   auto needs = [&](int k0) { return active && k0 < k_end && k0 + kPfKeys > k_begin; };
 
-  fetch(wg_begin);
-  commit(0);
-  if (stages > 1) fetch(wg_begin + kPfStage);
-  __syncthreads();
+  if (stages > 0) {
+    fetch(wg_first);
+    commit(0);
+    if (stages > 1) fetch(wg_first + kPfStage);
+    __syncthreads();
+  }
   int buf = 0;
   for (int t = 0; t < stages; ++t) {                   // stages is workgroup-uniform: every wave meets every barrier
-    const int k0 = wg_begin + t * kPfStage;
+    const int k0 = wg_first + t * kPfStage;
     if (t + 1 < stages) commit(buf ^ 1);
     if (t + 2 < stages) fetch(k0 + 2 * kPfStage);
     bool any = false;                                              // wave-uniform
@@ -608,6 +638,27 @@ prefill_attention_kernel(uint16_t* __restrict__ out, const uint16_t* __restrict_
 
   // ---- normalise and store: this lane holds query q_idx, O^T rows d = 32*b + (r&3) + 8*(r>>2) + 4*half
   const float l_tot = l_part + __shfl_xor(l_part, 32, 64);
+  if (CTX && num_parts > 1) {
+    // split form: this workgroup saw only some of the keys; leave (O, m, l) for the reduce kernel
+    if (q_idx < q_end) {
+      const int64_t idx = ((int64_t)part * cx.total_rows + row0 + q_idx) * num_heads + head;
+      float* po = cx.part_o + idx * HEAD;
+#pragma unroll
+      for (int b = 0; b < DB; ++b)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          const int d = 32 * b + 8 * r4 + 4 * half;
+          if (d < HEAD)
+            *reinterpret_cast<float4*>(po + d) =
+                make_float4(o[b][4 * r4], o[b][4 * r4 + 1], o[b][4 * r4 + 2], o[b][4 * r4 + 3]);
+        }
+      if (half == 0) {
+        cx.part_m[idx] = m_run;
+        cx.part_l[idx] = l_tot;
+      }
+    }
+    return;
+  }
   const float inv = 1.f / l_tot;
   if (q_idx < q_end) {
     uint16_t* op = out + (row0 + q_idx) * out_stride + (int64_t)head * HEAD;
@@ -628,6 +679,43 @@ prefill_attention_kernel(uint16_t* __restrict__ out, const uint16_t* __restrict_
   }
 }
 
+// Joins the parts of the split form: out = sum_p O_p 2^(m_p - m) / sum_p l_p 2^(m_p - m), m = max_p m_p.
+// One workgroup per query row; a thread takes 4 head elements of one head at a time.
+template <typename act_t>
+__global__ void __launch_bounds__(256)
+context_attention_reduce_kernel(uint16_t* __restrict__ out, const float* __restrict__ part_o,
+                                const float* __restrict__ part_m, const float* __restrict__ part_l,
+                                const int32_t* __restrict__ seq_starts, const int32_t* __restrict__ new_lens,
+                                int num_heads, int head_size, int num_parts, int64_t total_rows, int64_t out_stride) {
+  const int seq = blockIdx.y;
+  if ((int)blockIdx.x >= new_lens[seq]) return;
+  const int64_t row = (int64_t)seq_starts[seq] + blockIdx.x;
+  const int per_head = head_size / 4;
+  for (int c = threadIdx.x; c < num_heads * per_head; c += 256) {
+    const int head = c / per_head, d = (c - head * per_head) * 4;
+    float m = -INFINITY;
+    for (int p = 0; p < num_parts; ++p) m = fmaxf(m, part_m[((int64_t)p * total_rows + row) * num_heads + head]);
+    float l = 0.f;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int p = 0; p < num_parts; ++p) {
+      const int64_t idx = ((int64_t)p * total_rows + row) * num_heads + head;
+      const float mp = part_m[idx];
+      if (mp == -INFINITY) continue;                   // this part saw no key of the row
+      const float w = __builtin_amdgcn_exp2f(mp - m);
+      l = fmaf(part_l[idx], w, l);
+      const float4 o = *reinterpret_cast<const float4*>(part_o + idx * head_size + d);
+      acc.x = fmaf(o.x, w, acc.x);
+      acc.y = fmaf(o.y, w, acc.y);
+      acc.z = fmaf(o.z, w, acc.z);
+      acc.w = fmaf(o.w, w, acc.w);
+    }
+    const float inv = 1.f / l;
+    const uint32_t lo = (uint32_t)Conv<act_t>::from_float(acc.x * inv) | ((uint32_t)Conv<act_t>::from_float(acc.y * inv) << 16);
+    const uint32_t hi = (uint32_t)Conv<act_t>::from_float(acc.z * inv) | ((uint32_t)Conv<act_t>::from_float(acc.w * inv) << 16);
+    *reinterpret_cast<uint2*>(out + row * out_stride + (int64_t)head * head_size + d) = make_uint2(lo, hi);
+  }
+}
+
 template <typename act_t, int HEAD, bool CTX, int WAVES>
 int launch_prefill_w(void* out, const void* q, const void* k, const void* v, const int32_t* seq_starts,
                      const int32_t* seq_lens, int num_seqs, int max_seq_len, int num_heads, int num_kv_heads,
@@ -637,7 +725,11 @@ int launch_prefill_w(void* out, const void* q, const void* k, const void* v, con
   const int q_tiles = (max_seq_len + rows_per_wg - 1) / rows_per_wg;
   SW_CHECK_ARG((int64_t)q_tiles * num_heads * num_seqs < (int64_t)1 << 31, "prefill attention: %d x %d x %d workgroups",
                q_tiles, num_heads, num_seqs);
-  dim3 grid((unsigned)(q_tiles * num_heads * num_seqs));
+  // the split form needs the shared form of the context phase (see the kernel)
+  const int parts = (CTX && cx.num_parts > 1 && pf_dp(HEAD) == HEAD && cx.block_size % 8 == 0) ? cx.num_parts : 1;
+  SW_CHECK_ARG(parts == std::max(cx.num_parts, 1), "context_attention: head size %d / block size %d cannot be split",
+               HEAD, cx.block_size);
+  dim3 grid((unsigned)(q_tiles * num_heads * num_seqs), (unsigned)parts);
   const size_t smem = (size_t)pf_lds_bytes(HEAD);
   auto kern = prefill_attention_kernel<act_t, HEAD, CTX, WAVES>;
 
@@ -649,6 +741,12 @@ int launch_prefill_w(void* out, const void* q, const void* k, const void* v, con
       static_cast<const uint16_t*>(v), seq_starts, seq_lens, num_heads, num_kv_heads, scale, alibi, q_stride,
       k_stride, v_stride, out_stride, sliding_window, num_seqs, max_seq_len, cx);
   SW_CHECK_LAUNCH();
+  if (parts > 1) {
+    context_attention_reduce_kernel<act_t><<<dim3((unsigned)max_seq_len, (unsigned)num_seqs), 256, 0, stream>>>(
+        static_cast<uint16_t*>(out), cx.part_o, cx.part_m, cx.part_l, seq_starts, seq_lens, num_heads, HEAD, parts,
+        cx.total_rows, out_stride);
+    SW_CHECK_LAUNCH();
+  }
   return SW_OK;
 }
 
@@ -741,14 +839,15 @@ extern "C" int sw_prefill_attention(void* out, const void* query, const void* ke
                            sliding_window, act_dtype, nullptr, stream);
 }
 
-extern "C" int sw_context_attention(void* out, const void* query, const void* key, const void* value,
-                                    const void* key_cache, const void* value_cache, const int32_t* block_tables,
-                                    int max_blocks_per_seq, const int32_t* seq_starts, const int32_t* new_lens,
-                                    const int32_t* ctx_lens, int num_seqs, int max_new_len, int num_heads,
-                                    int num_kv_heads, int head_size, int block_size, float scale,
-                                    const float* alibi_slopes, int64_t q_stride, int64_t k_stride, int64_t v_stride,
-                                    int64_t out_stride, int64_t kv_block_stride, int64_t kv_head_stride,
-                                    int sliding_window, int act_dtype, void* stream) {
+static int context_attention_entry(void* out, const void* query, const void* key, const void* value,
+                                   const void* key_cache, const void* value_cache, const int32_t* block_tables,
+                                   int max_blocks_per_seq, const int32_t* seq_starts, const int32_t* new_lens,
+                                   const int32_t* ctx_lens, int num_seqs, int max_new_len, int num_heads,
+                                   int num_kv_heads, int head_size, int block_size, float scale,
+                                   const float* alibi_slopes, int64_t q_stride, int64_t k_stride, int64_t v_stride,
+                                   int64_t out_stride, int64_t kv_block_stride, int64_t kv_head_stride,
+                                   int sliding_window, int act_dtype, int64_t total_rows, int num_parts,
+                                   void* workspace, int64_t workspace_bytes, void* stream) {
   using namespace sw;
   SW_CHECK_ARG(key_cache && value_cache && block_tables && ctx_lens && max_blocks_per_seq > 0,
                "context_attention: NULL cache, block table or context lengths");
@@ -756,7 +855,7 @@ extern "C" int sw_context_attention(void* out, const void* query, const void* ke
   SW_CHECK_ARG(head_size % 8 == 0 && kv_block_stride % 8 == 0 && kv_head_stride % 8 == 0 &&
                    reinterpret_cast<uintptr_t>(key_cache) % 16 == 0 && reinterpret_cast<uintptr_t>(value_cache) % 16 == 0,
                "context_attention: the caches must be 16-byte aligned with strides in multiples of 8 elements");
-  PfContext cx;
+  PfContext cx = {};
   cx.k_cache = static_cast<const uint16_t*>(key_cache);
   cx.v_cache = static_cast<const uint16_t*>(value_cache);
   cx.block_tables = block_tables;
@@ -765,7 +864,71 @@ extern "C" int sw_context_attention(void* out, const void* query, const void* ke
   cx.block_size = block_size;
   cx.k_block_stride = cx.v_block_stride = kv_block_stride;
   cx.k_head_stride = cx.v_head_stride = kv_head_stride;
+  cx.num_parts = 1;
+  if (num_parts > 1) {
+    SW_CHECK_ARG(num_parts <= 64 && total_rows > 0 && workspace != nullptr &&
+                     reinterpret_cast<uintptr_t>(workspace) % 16 == 0 &&
+                     workspace_bytes >= sw_context_attention_split_workspace_bytes(num_parts, total_rows, num_heads, head_size),
+                 "context_attention_split: %d parts of %lld rows need a 16-byte aligned workspace of %lld bytes",
+                 num_parts, (long long)total_rows,
+                 (long long)sw_context_attention_split_workspace_bytes(num_parts, total_rows, num_heads, head_size));
+    const int64_t rows = (int64_t)num_parts * total_rows * num_heads;
+    cx.num_parts = num_parts;
+    cx.total_rows = total_rows;
+    cx.part_o = static_cast<float*>(workspace);
+    cx.part_m = cx.part_o + rows * head_size;
+    cx.part_l = cx.part_m + rows;
+  }
   return prefill_entry(out, query, key, value, seq_starts, new_lens, num_seqs, max_new_len, num_heads, num_kv_heads,
                        head_size, scale, alibi_slopes, q_stride, k_stride, v_stride, out_stride, sliding_window,
                        act_dtype, &cx, stream);
+}
+
+extern "C" int64_t sw_context_attention_split_workspace_bytes(int num_parts, int64_t total_rows, int num_heads,
+                                                             int head_size) {
+  if (num_parts <= 1) return 0;
+  return (int64_t)num_parts * total_rows * num_heads * (head_size + 2) * 4;
+}
+
+// How many workgroups should share the key stages of one (query tile, sequence, head): 1 (no split) when the launch
+// fills the chip by itself, the context is short, or the shapes need the unsplit form.
+extern "C" int sw_context_attention_split_parts(int num_seqs, int max_new_len, int num_heads, int head_size,
+                                                int block_size, int max_context_len) {
+  if (num_seqs <= 0 || max_new_len <= 0 || head_size % 32 != 0 || block_size % 8 != 0) return 1;
+  const int64_t workgroups = (int64_t)((max_new_len + 127) / 128) * num_heads * num_seqs;
+  if (workgroups >= 256 || max_context_len < 1024) return 1;
+  int parts = (int)std::min<int64_t>(8, 512 / workgroups);
+  parts = std::min(parts, max_context_len / 512);          // at least 8 stages of 64 keys per part
+  return std::max(parts, 1);
+}
+
+extern "C" int sw_context_attention(void* out, const void* query, const void* key, const void* value,
+                                    const void* key_cache, const void* value_cache, const int32_t* block_tables,
+                                    int max_blocks_per_seq, const int32_t* seq_starts, const int32_t* new_lens,
+                                    const int32_t* ctx_lens, int num_seqs, int max_new_len, int num_heads,
+                                    int num_kv_heads, int head_size, int block_size, float scale,
+                                    const float* alibi_slopes, int64_t q_stride, int64_t k_stride, int64_t v_stride,
+                                    int64_t out_stride, int64_t kv_block_stride, int64_t kv_head_stride,
+                                    int sliding_window, int act_dtype, void* stream) {
+  return context_attention_entry(out, query, key, value, key_cache, value_cache, block_tables, max_blocks_per_seq,
+                                 seq_starts, new_lens, ctx_lens, num_seqs, max_new_len, num_heads, num_kv_heads,
+                                 head_size, block_size, scale, alibi_slopes, q_stride, k_stride, v_stride, out_stride,
+                                 kv_block_stride, kv_head_stride, sliding_window, act_dtype, 0, 1, nullptr, 0, stream);
+}
+
+extern "C" int sw_context_attention_split(void* out, const void* query, const void* key, const void* value,
+                                          const void* key_cache, const void* value_cache, const int32_t* block_tables,
+                                          int max_blocks_per_seq, const int32_t* seq_starts, const int32_t* new_lens,
+                                          const int32_t* ctx_lens, int num_seqs, int max_new_len, int num_heads,
+                                          int num_kv_heads, int head_size, int block_size, float scale,
+                                          const float* alibi_slopes, int64_t q_stride, int64_t k_stride,
+                                          int64_t v_stride, int64_t out_stride, int64_t kv_block_stride,
+                                          int64_t kv_head_stride, int sliding_window, int act_dtype,
+                                          int64_t total_rows, int num_parts, void* workspace, int64_t workspace_bytes,
+                                          void* stream) {
+  return context_attention_entry(out, query, key, value, key_cache, value_cache, block_tables, max_blocks_per_seq,
+                                 seq_starts, new_lens, ctx_lens, num_seqs, max_new_len, num_heads, num_kv_heads,
+                                 head_size, block_size, scale, alibi_slopes, q_stride, k_stride, v_stride, out_stride,
+                                 kv_block_stride, kv_head_stride, sliding_window, act_dtype, total_rows, num_parts,
+                                 workspace, workspace_bytes, stream);
 }

@@ -71,6 +71,10 @@ _SIGNATURES = {
     "sw_kv_wait": [_c_void_p, _c_int, ctypes.c_int32, _c_i64, _c_void_p, _c_void_p],
     "sw_context_attention": [_c_void_p] * 7 + [_c_int] + [_c_void_p] * 3 + [_c_int] * 6 + [ctypes.c_float, _c_void_p]
                             + [_c_i64] * 6 + [_c_int, _c_int, _c_void_p],
+    "sw_context_attention_split": [_c_void_p] * 7 + [_c_int] + [_c_void_p] * 3 + [_c_int] * 6 + [ctypes.c_float, _c_void_p]
+                                  + [_c_i64] * 6 + [_c_int, _c_int, _c_i64, _c_int, _c_void_p, _c_i64, _c_void_p],
+    "sw_context_attention_split_parts": [_c_int] * 6,
+    "sw_context_attention_split_workspace_bytes": [_c_int, _c_i64, _c_int, _c_int],
     "sw_custom_ar_signal_bytes": [],
     "sw_custom_ar_init": [ctypes.POINTER(_c_void_p), _c_int, _c_int, _c_i64, _c_i64, _c_i64, _c_i64,
                           ctypes.POINTER(_c_void_p)],
@@ -91,7 +95,8 @@ _SIGNATURES = {
     "sw_awq_dequantize": [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p],
 }
 _RESTYPES = {"sw_quant_gemm_workspace_bytes": _c_i64, "sw_custom_ar_signal_bytes": _c_i64,
-             "sw_paged_attention_v2_static_max_bytes": _c_i64}     # everything else returns an int status
+             "sw_paged_attention_v2_static_max_bytes": _c_i64,
+             "sw_context_attention_split_workspace_bytes": _c_i64}     # everything else returns an int status
 
 _lib = None
 
@@ -100,7 +105,7 @@ def library_path() -> str:
     return _LIB_PATH
 
 
-ABI_VERSION = 6                # SW_ABI_VERSION of include/splitwise_hip.h this binding was written against
+ABI_VERSION = 7                # SW_ABI_VERSION of include/splitwise_hip.h this binding was written against
 
 
 def load_library() -> ctypes.CDLL:
@@ -364,12 +369,15 @@ def prefill_attention(out: torch.Tensor, query: torch.Tensor, key: torch.Tensor,
 def context_attention_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, o: torch.Tensor, k_cache: torch.Tensor,
                           v_cache: torch.Tensor, b_loc: torch.Tensor, b_start_loc: torch.Tensor,
                           b_seq_len: torch.Tensor, b_ctx_len: torch.Tensor, max_input_len: int,
-                          alibi_slopes: Optional[torch.Tensor] = None, sliding_window: Optional[int] = None) -> None:
+                          alibi_slopes: Optional[torch.Tensor] = None, sliding_window: Optional[int] = None,
+                          num_parts: Optional[int] = None) -> None:
     """Prompt attention over a cached prefix plus new tokens, with the argument list of the
     reference's Triton entry point (ops/prefix_prefill.py:621-632): q / o [T, H, D], k / v [T, KVH, D]
     (new tokens only), k_cache [blocks, KVH, D/8, bs, 8], v_cache [blocks, KVH, D, bs], b_loc the
     block table [B, max_blocks], b_start_loc the first new-token row of each sequence, b_seq_len
-    context + new tokens, b_ctx_len the cached tokens.  scale = D^-1/2 (:641)."""
+    context + new tokens, b_ctx_len the cached tokens.  scale = D^-1/2 (:641).
+    ``num_parts``: workgroups that share the keys of one (query tile, sequence, head); None lets the library
+    decide from the launch's shape (few new tokens over a long context leave most of the chip idle otherwise)."""
     _require_cuda(o, q, k, v, k_cache, v_cache, b_loc, b_start_loc, b_seq_len, b_ctx_len)
     for t in (o, q, k, v):
         if t.stride(2) != 1 or t.stride(1) != t.shape[2]:
@@ -388,14 +396,23 @@ def context_attention_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, o: 
     act = _act_dtype(q)
     if alibi_slopes is not None:
         alibi_slopes = alibi_slopes.to(device=q.device, dtype=torch.float32)
+    lib = load_library()
+    if num_parts is None:
+        num_parts = lib.sw_context_attention_split_parts(new.numel(), int(max_input_len), q.shape[1], head, block_size,
+                                                         table.shape[1] * block_size)
     with torch.cuda.device(q.device):
-        _check(load_library().sw_context_attention(
-            o.data_ptr(), q.data_ptr(), k.data_ptr(), v.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(),
-            table.data_ptr(), table.shape[1], starts.data_ptr(), new.data_ptr(), ctx.data_ptr(), new.numel(),
-            int(max_input_len), q.shape[1], k.shape[1], head, block_size, float(head) ** -0.5,
-            alibi_slopes.data_ptr() if alibi_slopes is not None else None, q.stride(0), k.stride(0), v.stride(0),
-            o.stride(0), v_cache.stride(0), v_cache.stride(1), int(sliding_window) if sliding_window else 0, act,
-            _stream(q)))
+        args = (o.data_ptr(), q.data_ptr(), k.data_ptr(), v.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(),
+                table.data_ptr(), table.shape[1], starts.data_ptr(), new.data_ptr(), ctx.data_ptr(), new.numel(),
+                int(max_input_len), q.shape[1], k.shape[1], head, block_size, float(head) ** -0.5,
+                alibi_slopes.data_ptr() if alibi_slopes is not None else None, q.stride(0), k.stride(0), v.stride(0),
+                o.stride(0), v_cache.stride(0), v_cache.stride(1), int(sliding_window) if sliding_window else 0, act)
+        if num_parts > 1:
+            nbytes = int(lib.sw_context_attention_split_workspace_bytes(num_parts, q.shape[0], q.shape[1], head))
+            workspace = torch.empty(nbytes // 4, dtype=torch.float32, device=q.device)
+            _check(lib.sw_context_attention_split(*args, q.shape[0], int(num_parts), workspace.data_ptr(), nbytes,
+                                                  _stream(q)))
+        else:
+            _check(lib.sw_context_attention(*args, _stream(q)))
 
 
 def _rows(t: torch.Tensor):
