@@ -209,6 +209,7 @@ def test_split_form_is_chosen_for_few_new_tokens_over_a_long_context_and_refused
     # 512 new tokens on a 3584-token context, 32 heads: 128 workgroups -> 4 parts; a full launch is left alone
     assert lib.sw_context_attention_split_parts(1, 512, 32, 128, 16, 3584) == 4
     assert lib.sw_context_attention_split_parts(1, 64, 32, 128, 16, 8192) == 8
+    assert lib.sw_context_attention_split_parts(2, 512, 32, 128, 16, 3584) == 2
     assert lib.sw_context_attention_split_parts(4, 512, 32, 128, 16, 3584) == 1
     assert lib.sw_context_attention_split_parts(1, 512, 32, 128, 16, 512) == 1
     assert lib.sw_context_attention_split_parts(1, 512, 32, 80, 16, 3584) == 1      # head sizes off multiples of 32

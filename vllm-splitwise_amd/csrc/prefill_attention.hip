@@ -896,8 +896,10 @@ extern "C" int sw_context_attention_split_parts(int num_seqs, int max_new_len, i
                                                 int block_size, int max_context_len) {
   if (num_seqs <= 0 || max_new_len <= 0 || head_size % 32 != 0 || block_size % 8 != 0) return 1;
   const int64_t workgroups = (int64_t)((max_new_len + 127) / 128) * num_heads * num_seqs;
-  if (workgroups >= 256 || max_context_len < 1024) return 1;
-  int parts = (int)std::min<int64_t>(8, 512 / workgroups);
+  // measured on 1 x 512-on-3584 (128 workgroups: 184 us unsplit, 91 us in 4 parts), 2 x 512-on-3584 (256: 185 ->
+  // 133 us in 2), 128-on-8192 (32: 369 -> 89 us in 8); launches of 512 workgroups are best left alone
+  if (workgroups >= 384 || max_context_len < 1024) return 1;
+  int parts = (int)std::min<int64_t>(8, (512 + workgroups / 2) / workgroups);
   parts = std::min(parts, max_context_len / 512);          // at least 8 stages of 64 keys per part
   return std::max(parts, 1);
 }
