@@ -332,3 +332,56 @@ def test_pipelined_steps_generate_the_same_tokens(enforce_eager, blocks):
         del llm
         torch.cuda.empty_cache()
     assert results[0] == results[1]
+
+
+@pytest.mark.parametrize("pipeline,blocks", [(False, 256), (True, 256), (False, 40)])
+def test_parallel_sampling_forks_share_the_prompt_and_copy_on_write(pipeline, blocks):
+    """n > 1 inside one request (vllm/engine/llm_engine.py:424-534, Scheduler.fork_seq, block_manager.py:302-309):
+    the prompt step draws best_of tokens, every further sequence is a fork of the prompt sequence that shares
+    its blocks until one of them writes (the last, partly filled prompt block is copied first).  With top_k = 1
+    the random-sampling path is deterministic, so every one of the n outputs must equal the greedy output of the
+    same prompt -- which it only does if every fork's cache holds the right keys and values.  A pipelined engine
+    runs plain steps while such a request is alive and goes back to pipelined steps afterwards; with 40 blocks the
+    groups are preempted (swapped out and in again as groups)."""
+    from splitwise_amd import LLM, SamplingParams
+    random.seed(6)
+    llm = LLM("llama-tiny", enforce_eager=False, num_gpu_blocks_override=blocks, max_num_seqs=12, max_model_len=256,
+              swap_space=0.05, pipeline_steps=pipeline)
+    engine = llm.llm_engine
+    prompts = [[random.randrange(512) for _ in range(n)] for n in (5, 33, 64, 17, 40)]
+    greedy = llm.generate(prompt_token_ids=prompts, sampling_params=SamplingParams(temperature=0.0, max_tokens=24))
+    want = [o.outputs[0].token_ids for o in greedy]
+    # n = 3 of best_of = 4, interleaved with plain greedy requests that keep the pipelined path busy
+    forked = SamplingParams(n=3, best_of=4, temperature=1.0, top_k=1, max_tokens=24, seed=3)
+    plain = SamplingParams(temperature=0.0, max_tokens=24)
+    for i, prompt in enumerate(prompts):
+        engine.add_request(f"f{i}", None, forked, prompt_token_ids=prompt)
+        engine.add_request(f"g{i}", None, plain, prompt_token_ids=prompt)
+    done = {}
+    steps = 0
+    while engine.has_unfinished_requests():
+        for out in engine.step():
+            if out.finished:
+                done[out.request_id] = out
+        steps += 1
+        assert steps < 5000
+    for i in range(len(prompts)):
+        out = done[f"f{i}"]
+        assert [c.index for c in out.outputs] == [0, 1, 2]
+        for c in out.outputs:
+            assert c.token_ids == want[i] and c.finish_reason == "length", (i, c.index)
+        assert done[f"g{i}"].outputs[0].token_ids == want[i]
+    assert not engine._multi_sample_requests
+    assert engine.scheduler.block_manager.get_num_free_gpu_blocks() == blocks          # every fork's blocks came back
+    if blocks == 40:
+        assert engine.scheduler.num_preemptions > 0
+    # diverging samples: best_of = 3 of which the 2 most likely come back, ordered by cumulative log-probability
+    outs = llm.generate(prompt_token_ids=prompts[:2],
+                        sampling_params=SamplingParams(n=2, best_of=3, temperature=1.0, top_k=4, max_tokens=10, seed=7))
+    for out in outs:
+        assert len(out.outputs) == 2 and all(len(c.token_ids) == 10 for c in out.outputs)
+        assert out.outputs[0].cumulative_logprob >= out.outputs[1].cumulative_logprob
+    with pytest.raises(ValueError, match="best_of must be 1 when using greedy"):
+        SamplingParams(n=2, temperature=0.0)
+    del llm
+    torch.cuda.empty_cache()

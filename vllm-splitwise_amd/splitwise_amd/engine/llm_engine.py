@@ -80,6 +80,9 @@ class LLMEngine:
         self._prompt_inflight = None    # (pending samples, scheduler outputs, request ids, lane)
         self._decode_inflight: List[Optional[tuple]] = [None] * lanes   # per lane: (scheduler outputs, [(group, sequence)])
         self._free_later: List[List[Sequence]] = [[] for _ in range(lanes)]
+        # requests with best_of > 1 that are alive: while there are any, a pipelined engine runs plain steps (a
+        # fork needs the sampled tokens on the host before the next step can be laid out)
+        self._multi_sample_requests: set = set()
         self._next_prompt_lane = 0
         if (lanes > 1 or self.staged_prompt_cache) and not self.pipeline_split:
             raise NotImplementedError("several token pools / a staged prompt cache need pipeline_steps and an "
@@ -136,8 +139,14 @@ class LLMEngine:
             if self.tokenizer is None:
                 raise ValueError("prompt_token_ids must be given: no tokenizer is attached to this engine")
             prompt_token_ids = self.tokenizer.encode(prompt)
-        if sampling_params.n != 1 or sampling_params.best_of != 1:
-            raise NotImplementedError("n > 1 / best_of > 1 are outside the scope of this build")
+        if sampling_params.best_of != 1:
+            # several sequences forked from one prompt (llm_engine.py:424-534).  Their blocks are shared copy-on-write
+            # inside ONE cache; split pools would have to hand every fork's slot over, which the reference's
+            # scheduler does not do either (its slot map only knows sequences that were allocated as prompts)
+            if self.parallel_config.sep_prompt_token:
+                raise NotImplementedError("n > 1 / best_of > 1 with split prompt / token pools; the HTTP front "
+                                          "serves n as n requests")
+            self._multi_sample_requests.add(request_id)
         eos = getattr(self.tokenizer, "eos_token_id", None)
         seq = Sequence(self.seq_counter, prompt, list(prompt_token_ids), self.cache_config.block_size, eos)
         self.seq_counter += 1
@@ -145,6 +154,7 @@ class LLMEngine:
 
     def abort_request(self, request_id: Union[str, Iterable[str]]) -> None:
         self.scheduler.abort_seq_group(request_id)
+        self._multi_sample_requests.difference_update([request_id] if isinstance(request_id, str) else request_id)
 
     def get_num_unfinished_requests(self) -> int:
         return self.scheduler.get_num_unfinished_seq_groups()
@@ -220,6 +230,12 @@ class LLMEngine:
             for group in scheduled:
                 scheduler.mark_blocks_as_computed(group)
         for group, out in zip(scheduled, output):
+            if group.sampling_params.best_of > 1:
+                self._process_forking_group(group, out, scheduler)
+                if group.is_finished():
+                    self._multi_sample_requests.discard(group.request_id)
+                group.maybe_set_first_token_time(wall)
+                continue
             seq = group.get_seqs(status=SequenceStatus.RUNNING)[0]
             sample = out.samples[0]
             seq.append_token_id(sample.output_token, sample.logprobs)
@@ -234,6 +250,43 @@ class LLMEngine:
         if self.stat_logger is not None:
             self.stat_logger.log(self._get_stats(scheduler_outputs, scheduled, now))
         return request_outputs
+
+    def _process_forking_group(self, group: SequenceGroup, out, scheduler: Scheduler) -> None:
+        """A request with best_of > 1 (no beam search): vllm/engine/llm_engine.py:424-534.  The prompt step returns
+        best_of samples of the prompt sequence: all but the last become forks of it (their blocks shared
+        copy-on-write, Scheduler.fork_seq), the last continues the prompt sequence itself; from then on every
+        running sequence of the group gets the one sample that names it as its parent."""
+        params = group.sampling_params
+        parents = group.get_seqs(status=SequenceStatus.RUNNING)
+        by_parent = {parent.seq_id: [] for parent in parents}
+        for sample in out.samples:
+            by_parent[sample.parent_seq_id].append(sample)
+        children = []                                        # (sequence, its parent)
+        for parent in parents:
+            samples = by_parent[parent.seq_id]
+            if not samples:                                  # nothing continues this sequence (llm_engine.py:446-452)
+                parent.status = SequenceStatus.FINISHED_ABORTED
+                group.remove(parent.seq_id)
+                scheduler.free_seq(parent)
+                continue
+            for sample in samples[:-1]:
+                child = parent.fork(self.seq_counter)
+                self.seq_counter += 1
+                child.append_token_id(sample.output_token, sample.logprobs)
+                children.append((child, parent))
+            parent.append_token_id(samples[-1].output_token, samples[-1].logprobs)
+            children.append((parent, parent))
+        for seq, _ in children:
+            self._decode_sequence(seq, params)
+            self._check_stop(seq, params)
+        for seq, parent in children:
+            if seq is not parent:
+                group.add(seq)
+                if not seq.is_finished():
+                    scheduler.fork_seq(parent, seq)
+        for seq, parent in children:                         # parents last: their forks share their blocks
+            if seq is parent and seq.is_finished():
+                scheduler.free_seq(seq)
 
     def _step_split(self) -> List[RequestOutput]:
         """One decode step on the token pool and one prompt step on the prompt pool, in flight
@@ -479,7 +532,10 @@ class LLMEngine:
         if self.overlap_pools:
             return self._step_split()
         if self.pipeline_steps:
-            return self._step_pipelined()
+            if not self._multi_sample_requests:
+                return self._step_pipelined()
+            if self._inflight is not None:                   # finish the step in flight, then go on step by step
+                return self._resolve_inflight()
         metas, scheduler_outputs = self.scheduler.schedule()
         self.last_scheduled_prompt_run = bool(scheduler_outputs.prompt_run) and not scheduler_outputs.is_empty()
         if not scheduler_outputs.is_empty():

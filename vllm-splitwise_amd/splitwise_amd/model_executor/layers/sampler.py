@@ -22,7 +22,7 @@ class SamplingMetadata:
     def __init__(self, seq_groups: Optional[List[Tuple[List[int], SamplingParams]]],
                  seq_data: Optional[Dict[int, SequenceData]], prompt_lens: Optional[List[int]],
                  selected_token_indices: torch.Tensor, generators=None, perform_sampling: bool = True,
-                 defer: bool = False) -> None:
+                 defer: bool = False, is_prompt: Optional[List[bool]] = None) -> None:
         self.seq_groups = seq_groups
         self.seq_data = seq_data
         self.prompt_lens = prompt_lens
@@ -30,6 +30,8 @@ class SamplingMetadata:
         self.generators = generators
         self.perform_sampling = perform_sampling
         self.defer = defer          # leave the sampled tokens on the device; the caller resolves them later
+        # per sequence group: a prompt step?  (a prompt with best_of > 1 draws best_of tokens from its one row)
+        self.is_prompt = is_prompt
 
 
 def _host_to_device(values, dtype: torch.dtype, device: torch.device) -> torch.Tensor:
@@ -40,21 +42,28 @@ def _host_to_device(values, dtype: torch.dtype, device: torch.device) -> torch.T
     return t.to(device)
 
 
-def _build_output(seq_groups, ids: List[int], chosen_lp: Optional[List[float]], top=None) -> SamplerOutput:
+def _build_output(seq_groups, ids: List[int], chosen_lp: Optional[List[float]], top=None,
+                  extra=None) -> SamplerOutput:
     """``top``: (log-probs, token ids) of the most likely tokens of every row, as nested lists, when some
     request asked for ``logprobs``; a row's dict holds the sampled token and its request's top-k
-    (sampler.py:540-587 of the reference)."""
+    (sampler.py:540-587 of the reference).  ``extra``: {row: (token ids, log-probs)} of the further samples a
+    prompt with best_of > 1 draws from its row; they all name the prompt sequence as their parent
+    (sampler.py:367-369)."""
     outputs: List[SequenceGroupOutput] = []
     row = 0
     for seq_ids, params in seq_groups:
         samples = []
         for seq_id in seq_ids:
             lp = 0.0 if chosen_lp is None else chosen_lp[row]
-            entry = {ids[row]: Logprob(lp)}
-            if top is not None and params.logprobs:
-                for tok_lp, tok in zip(top[0][row][:params.logprobs], top[1][row][:params.logprobs]):
-                    entry.setdefault(tok, Logprob(tok_lp))
-            samples.append(SequenceOutput(seq_id, ids[row], entry))
+            drawn = [(ids[row], lp)]
+            if extra is not None and row in extra:
+                drawn += list(zip(*extra[row]))
+            for tok_id, tok_lp in drawn:
+                entry = {tok_id: Logprob(tok_lp)}
+                if top is not None and params.logprobs:
+                    for t_lp, tok in zip(top[0][row][:params.logprobs], top[1][row][:params.logprobs]):
+                        entry.setdefault(tok, Logprob(t_lp))
+                samples.append(SequenceOutput(seq_id, tok_id, entry))
             row += 1
         outputs.append(SequenceGroupOutput(samples, None))
     return SamplerOutput(outputs=outputs)
@@ -238,8 +247,24 @@ class Sampler(nn.Module):
             if most > 0:
                 top = torch.topk(logprobs, min(most, logprobs.shape[1]), dim=-1)
                 top = (top.values, top.indices)
+        # a prompt with best_of > 1: best_of - 1 further independent draws from its row (the reference draws
+        # best_of columns of one multinomial call, sampler.py:356-369)
+        extra = None
+        if md.is_prompt is not None and not all_greedy:
+            row = 0
+            for (seq_ids, params), prompt in zip(md.seq_groups, md.is_prompt):
+                if prompt and params.best_of > 1:
+                    gen = (md.generators or {}).get(row)
+                    more = torch.multinomial(probs[row], params.best_of - 1, replacement=True, generator=gen)
+                    extra = extra or {}
+                    extra[row] = (more, logprobs[row].gather(0, more))
+                row += len(seq_ids)
         if md.defer:
+            if extra is not None:
+                raise NotImplementedError("best_of > 1 cannot leave its samples on the device (pipelined steps)")
             return PendingSamples(md.seq_groups, next_ids, chosen_lp, top)
         # the one device -> host sync of the step
+        if extra is not None:
+            extra = {row: (toks.tolist(), lps.tolist()) for row, (toks, lps) in extra.items()}
         return _build_output(md.seq_groups, next_ids.tolist(), None if chosen_lp is None else chosen_lp.tolist(),
-                             None if top is None else (top[0].tolist(), top[1].tolist()))
+                             None if top is None else (top[0].tolist(), top[1].tolist()), extra)

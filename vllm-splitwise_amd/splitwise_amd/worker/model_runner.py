@@ -286,7 +286,8 @@ class ModelRunner:
                     generators[r] = meta.state.generator
             row += n_rows
         return SamplingMetadata(seq_groups, seq_data, None,
-                                self._to_device(np.asarray(selected, dtype=np.int64), torch.long), generators)
+                                self._to_device(np.asarray(selected, dtype=np.int64), torch.long), generators,
+                                is_prompt=[meta.is_prompt for meta in metas])
 
     # --------------------------------------------------------------- execution
     @torch.inference_mode()
