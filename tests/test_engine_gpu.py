@@ -334,14 +334,14 @@ def test_pipelined_steps_generate_the_same_tokens(enforce_eager, blocks):
     assert results[0] == results[1]
 
 
-@pytest.mark.parametrize("pipeline,blocks", [(False, 256), (True, 256), (False, 40)])
+@pytest.mark.parametrize("pipeline,blocks", [(False, 256), (True, 256), (False, 24)])
 def test_parallel_sampling_forks_share_the_prompt_and_copy_on_write(pipeline, blocks):
     """n > 1 inside one request (vllm/engine/llm_engine.py:424-534, Scheduler.fork_seq, block_manager.py:302-309):
     the prompt step draws best_of tokens, every further sequence is a fork of the prompt sequence that shares
     its blocks until one of them writes (the last, partly filled prompt block is copied first).  With top_k = 1
     the random-sampling path is deterministic, so every one of the n outputs must equal the greedy output of the
     same prompt -- which it only does if every fork's cache holds the right keys and values.  A pipelined engine
-    runs plain steps while such a request is alive and goes back to pipelined steps afterwards; with 40 blocks the
+    runs plain steps while such a request is alive and goes back to pipelined steps afterwards; with 24 blocks the
     groups are preempted (swapped out and in again as groups)."""
     from splitwise_amd import LLM, SamplingParams
     random.seed(6)
@@ -373,8 +373,8 @@ def test_parallel_sampling_forks_share_the_prompt_and_copy_on_write(pipeline, bl
         assert done[f"g{i}"].outputs[0].token_ids == want[i]
     assert not engine._multi_sample_requests
     assert engine.scheduler.block_manager.get_num_free_gpu_blocks() == blocks          # every fork's blocks came back
-    if blocks == 40:
-        assert engine.scheduler.num_preemptions > 0
+    if blocks == 24:
+        assert getattr(engine.scheduler, "num_preemptions", 0) > 0
     # diverging samples: best_of = 3 of which the 2 most likely come back, ordered by cumulative log-probability
     outs = llm.generate(prompt_token_ids=prompts[:2],
                         sampling_params=SamplingParams(n=2, best_of=3, temperature=1.0, top_k=4, max_tokens=10, seed=7))
