@@ -226,8 +226,10 @@ int sw_kv_wait(const int32_t* flags, int slot, int32_t epoch, int64_t max_spins,
 
 /* ------------------------------------------------ int4 weight-only linear layers
  * fp16 activations and scales only (vllm/model_executor/layers/quantization/gptq.py:50-51,
- * awq.py:45-46); 4-bit weights only (the reference's 2/3/8-bit GPTQ kernels are not provided:
- * SW_ERR_INVALID).  W[k][n] = fp16((q - zero) * scale); C = A.W accumulated in fp32.
+ * awq.py:45-46); 4-bit weights, and for the three sw_gptq_* entry points also 8-bit ones (qweight int32 [K/4, N],
+ * byte i of a word = row 4r+i; qzeros int32 [groups, N/4]; csrc/quantization/gptq/qdq_8.cuh, q_gemm.cu:601-735,
+ * :810-918, :1989-2029) through plain kernels without the matrix cores; the reference's 2/3-bit GPTQ kernels are
+ * not provided: SW_ERR_INVALID.  W[k][n] = fp16((q - zero) * scale); C = A.W accumulated in fp32.
  *
  * Workspace: the fused GEMMs split k across workgroups and combine fp32 partial tiles in
  * device memory.  `workspace` must hold at least 16 KiB, whose first 16 KiB are ZERO the first

@@ -3,7 +3,7 @@
 TEST INFRASTRUCTURE ONLY: imported by tests/, smoke() and the cpu_baseline leg of bench.py,
 never by the product path.
 
-PARITY UNPINNED: the reference holds no test or golden vector for 4-bit GPTQ or for AWQ (its
+PARITY UNPINNED: the reference holds no test or golden vector for 4-bit or 8-bit dense GPTQ or for AWQ (its
 only quantization test, tests/kernels/test_dequant.py:60-112, is 8-bit MoE and needs Triton
 and a GPU), and its CUDA kernels cannot run here.  Every function below is therefore a
 restatement of the cited CUDA source, checked only for self-consistency (pack -> dequantize
@@ -139,6 +139,77 @@ def gptq_gemm(a: np.ndarray, qweight, qzeros, scales, g_idx, use_exllama: bool) 
     above 50 rows, q_gemm.cu:1712-1726, up to summation order)."""
     w = gptq_dequant(qweight, qzeros, scales, g_idx, use_exllama).astype(np.float32)
     return a.astype(np.float32) @ w
+
+
+# ------------------------------------------------------------------------------- GPTQ, 8-bit
+def gptq8_pack(q: np.ndarray, zeros: np.ndarray):
+    """q [K, N] in 0..255, zeros [G, N] in 1..256 (the effective zero point) -> (qweight [K/4, N] with byte i of a
+    word = row 4r+i, qzeros [G, N/4] with byte n % 4 = zero - 1) as int32 arrays in checkpoint layout."""
+    assert zeros.min() >= 1 and zeros.max() <= 256 and q.min() >= 0 and q.max() <= 255
+    k, n = q.shape
+    g = zeros.shape[0]
+    qw = np.zeros((k // 4, n), dtype=np.uint32)
+    qq = q.astype(np.uint32).reshape(k // 4, 4, n)
+    for i in range(4):
+        qw |= qq[:, i, :] << np.uint32(8 * i)
+    qz = np.zeros((g, n // 4), dtype=np.uint32)
+    zz = (zeros - 1).astype(np.uint32).reshape(g, n // 4, 4)
+    for c in range(4):
+        qz |= zz[:, :, c] << np.uint32(8 * c)
+    return qw.view(np.int32), qz.view(np.int32)
+
+
+def _unpack8_rows(w: np.ndarray) -> np.ndarray:
+    r, n = w.shape
+    w = w.view(np.uint32)
+    out = np.empty((r, 4, n), dtype=np.int32)
+    for i in range(4):
+        out[:, i, :] = (w >> np.uint32(8 * i)) & np.uint32(0xFF)
+    return out.reshape(r * 4, n)
+
+
+def gptq8_shuffle(qweight: np.ndarray, q_perm=None) -> np.ndarray:
+    """shuffle_exllama_weight for 8-bit weights: the in-word order does not change (shuffle_8bit_4 is empty,
+    qdq_8.cuh:14-21); with a permutation new row i = old row q_perm[i] (make_sequential_8bit_kernel,
+    q_gemm.cu:1989-2029)."""
+    if q_perm is None:
+        return qweight.copy()
+    q = _unpack8_rows(qweight)[np.asarray(q_perm, dtype=np.int64)]
+    k, n = q.shape
+    out = np.zeros((k // 4, n), dtype=np.uint32)
+    qq = q.astype(np.uint32).reshape(k // 4, 4, n)
+    for i in range(4):
+        out |= qq[:, i, :] << np.uint32(8 * i)
+    return out.view(np.int32)
+
+
+def gptq8_dequant(qweight: np.ndarray, qzeros: np.ndarray, scales: np.ndarray, g_idx, use_exllama: bool) -> np.ndarray:
+    """fp16 [K, N] in ORIGINAL row order: dq_ns(q, zero + 1) * scale (qdq_8.cuh:23-38, qdq_util.cuh:42-46;
+    reconstruct_exllama_8bit_kernel q_gemm.cu:810-918, reconstruct_gptq_kernel :1517-1561).  ``g_idx`` as in
+    gptq_dequant."""
+    groups, n = scales.shape
+    z = qzeros.view(np.uint32)
+    zeros = np.empty((groups, n // 4, 4), dtype=np.int32)
+    for c in range(4):
+        zeros[:, :, c] = (z >> np.uint32(8 * c)) & np.uint32(0xFF)
+    zeros = zeros.reshape(groups, n) + 1
+    q = _unpack8_rows(qweight)
+    k = q.shape[0]
+    if use_exllama or g_idx is None:
+        grp = np.arange(k) // (k // groups)
+    else:
+        grp = np.asarray(g_idx, dtype=np.int64)
+    diff = (q - zeros[grp]).astype(np.float16)                                 # |difference| <= 256: exact
+    w = diff * scales.astype(np.float16)[grp]                                  # one fp16 rounding
+    if use_exllama and g_idx is not None:
+        out = np.empty_like(w)
+        out[np.asarray(g_idx, dtype=np.int64)] = w
+        return out
+    return w
+
+
+def gptq8_gemm(a: np.ndarray, qweight, qzeros, scales, g_idx, use_exllama: bool) -> np.ndarray:
+    return a.astype(np.float32) @ gptq8_dequant(qweight, qzeros, scales, g_idx, use_exllama).astype(np.float32)
 
 
 # ------------------------------------------------------------------------------- AWQ

@@ -69,3 +69,27 @@ def test_awq_nibble_order_known_word():
     # logical columns 0..7 hold 0..7: column c sits in nibble [0,4,1,5,2,6,3,7][c]
     qweight, _ = quant.awq_pack(np.arange(8).reshape(1, 8), np.zeros((1, 8), dtype=np.int64))
     assert qweight.view(np.uint32)[0, 0] == 0x75316420
+
+
+def test_gptq_8bit_pack_shuffle_dequant_round_trip():
+    """8-bit GPTQ restatement (qdq_8.cuh, q_gemm.cu:810-918, :1989-2029): packing then reconstruction gives
+    (q - zero) * scale with the zero point stored minus one, the "shuffle" leaves the word order alone, and the
+    act-order form (rows gathered by the permutation, reconstruction scattered back) equals the plain form."""
+    import numpy as np
+    from oracle import quant
+    rng = np.random.default_rng(0)
+    k, n, group = 128, 24, 32
+    q = rng.integers(0, 256, size=(k, n))
+    zeros = rng.integers(1, 257, size=(k // group, n))
+    scales = (rng.uniform(0.5, 1.5, size=(k // group, n)) * 1e-3).astype(np.float16)
+    qweight, qzeros = quant.gptq8_pack(q, zeros)
+    assert qweight.shape == (k // 4, n) and qzeros.shape == (k // group, n // 4)
+    grp = np.arange(k) // group
+    want = (q - zeros[grp]).astype(np.float16) * scales[grp]
+    assert np.array_equal(quant.gptq8_dequant(quant.gptq8_shuffle(qweight), qzeros, scales, None, True), want)
+    g_idx = rng.permutation(grp).astype(np.int32)
+    plain = quant.gptq8_dequant(qweight, qzeros, scales, g_idx, False)
+    perm = np.argsort(g_idx, kind="stable")
+    assert np.array_equal(quant.gptq8_dequant(quant.gptq8_shuffle(qweight, perm), qzeros, scales, perm, True), plain)
+    # the extremes of the difference are exact in fp16
+    assert float((np.int32(0) - np.int32(256))) == float(np.float16(-256)) and float(np.float16(254)) == 254.0

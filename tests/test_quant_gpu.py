@@ -284,3 +284,78 @@ def test_int4_layers_keep_their_fp16_weight_for_many_row_calls():
     import gc
     gc.collect()
     assert dense_copy._used_bytes == used                           # the budget comes back with the layer
+
+
+# ----------------------------------------------------------------------------- GPTQ, 8-bit weights
+def _gptq8_case(k, n, group, seed, act_order=False):
+    rng = np.random.default_rng(seed)
+    q = rng.integers(0, 256, size=(k, n))
+    groups = k // group
+    zeros = rng.integers(1, 257, size=(groups, n))
+    scales = (rng.uniform(0.5, 1.5, size=(groups, n)) * 1e-3).astype(np.float16)
+    g_idx = np.arange(k) // group
+    if act_order:
+        g_idx = rng.permutation(g_idx)
+    qweight, qzeros = quant.gptq8_pack(q, zeros)
+    return qweight, qzeros, scales, g_idx.astype(np.int32)
+
+
+@pytest.mark.parametrize("mode", ["exllama", "exllama_act_order", "plain"])
+def test_gptq_8bit_shuffle_and_dequant_bit_exact(mode):
+    """8-bit weights (qdq_8.cuh, q_gemm.cu:810-918, :1989-2029): the row gather and the reconstruction against the
+    restatement, bit for bit; zero points over the whole range 1..256 (the difference q - zero spans -256..254)."""
+    from splitwise_amd import _C
+    k, n, group = 512, 264, 64
+    qweight, qzeros, scales, g_idx = _gptq8_case(k, n, group, 21, act_order=mode != "exllama")
+    none = torch.empty((1, 1), device="meta")
+    if mode == "plain":
+        got = _C.ops.dequant_gptq(_dev(qweight), _dev(qzeros), _dev(scales), _dev(g_idx), 8, False)
+        ref = quant.gptq8_dequant(qweight, qzeros, scales, g_idx, False)
+    else:
+        perm = np.argsort(g_idx, kind="stable").astype(np.int32) if mode == "exllama_act_order" else None
+        dev = _dev(qweight)
+        _C.ops.gptq_shuffle(dev, _dev(perm) if perm is not None else none, 8)
+        w = quant.gptq8_shuffle(qweight, perm)
+        assert np.array_equal(dev.cpu().numpy(), w)
+        got = _C.ops.dequant_gptq(dev, _dev(qzeros), _dev(scales), _dev(perm) if perm is not None else none, 8, True)
+        ref = quant.gptq8_dequant(w, qzeros, scales, perm, True)
+    assert np.array_equal(got.cpu().numpy().view(np.uint16), ref.view(np.uint16))
+
+
+@pytest.mark.parametrize("m,k,n,group", [(1, 512, 256, 128), (9, 1024, 520, 64), (24, 512, 132, 32), (70, 512, 136, 128)])
+def test_gptq_8bit_gemm(m, k, n, group):
+    """The fused kernel (up to 24 rows) and reconstruction + dense GEMM (above), plain and act-order forms."""
+    from splitwise_amd import _C
+    qweight, qzeros, scales, g_idx = _gptq8_case(k, n, group, 5 * m + n, act_order=True)
+    a = np.random.default_rng(m).standard_normal((m, k)).astype(np.float16)
+    none = torch.empty((1, 1), device="meta")
+    plain_q, plain_z, plain_s, _ = _gptq8_case(k, n, group, 5 * m + n)
+    got = _C.ops.gptq_gemm(_dev(a), _dev(plain_q), _dev(plain_z), _dev(plain_s), none, True, 8)
+    _close(got, quant.gptq8_gemm(a, plain_q, plain_z, plain_s, None, True))
+    perm = np.argsort(g_idx, kind="stable").astype(np.int32)
+    w = quant.gptq8_shuffle(qweight, perm)
+    got = _C.ops.gptq_gemm(_dev(a), _dev(w), _dev(qzeros), _dev(scales), _dev(perm), True, 8)
+    ref = quant.gptq8_gemm(a, w, qzeros, scales, perm, True)
+    _close(got, ref)
+    got2 = _C.ops.gptq_gemm(_dev(a), _dev(qweight), _dev(qzeros), _dev(scales), _dev(g_idx), False, 8)
+    _close(got2, ref)
+
+
+def test_gptq_8bit_linear_method():
+    """GPTQLinearMethod with weight_bits = 8: parameter shapes of the checkpoint format (pack factor 4), the lazy
+    shuffle, the fused path and the many-row path."""
+    from splitwise_amd.model_executor.layers.quantization.gptq import GPTQConfig
+    k, n, group = 512, 256, 128
+    method = GPTQConfig(8, group, False).get_linear_method()
+    weights = method.create_weights(k, n, k, n, torch.float16)
+    assert weights["qweight"].shape == (k // 4, n) and weights["qzeros"].shape == (k // group, n // 4)
+    qweight, qzeros, scales, _ = _gptq8_case(k, n, group, 33)
+    weights = {key: (val.cuda() if isinstance(val, torch.Tensor) else val) for key, val in weights.items()}
+    weights["qweight"].data.copy_(_dev(qweight))
+    weights["qzeros"].data.copy_(_dev(qzeros))
+    weights["scales"].data.copy_(_dev(scales))
+    for m in (3, 100):
+        a = np.random.default_rng(m).standard_normal((m, k)).astype(np.float16)
+        _close(method.apply_weights(weights, _dev(a)), quant.gptq8_gemm(a, qweight, qzeros, scales, None, True))
+    with pytest.raises(ValueError, match="4-bit and 8-bit"):
+        GPTQConfig(3, group, False)

@@ -920,6 +920,88 @@ __global__ void gptq_dequant_kernel(uint16_t* __restrict__ out, const uint32_t* 
   }
 }
 
+// ------------------------------------------------------------------ GPTQ, 8-bit weights
+// csrc/quantization/gptq/qdq_8.cuh and the 8-bit kernels of q_gemm.cu (:601-735 fused GEMM, :810-918 reconstruction,
+// :1989-2029 row gather): a word holds 4 consecutive k of one column, byte i = row 4r + i, in the same order before
+// and after "shuffling" (shuffle_8bit_4 is empty); qzeros [groups, N/4], byte n % 4 = zero - 1.  No configuration
+// of the benchmark uses 8-bit weights: the kernels below are plain ones (no matrix cores), and the Python operator
+// reconstructs and calls a dense GEMM above 24 rows as the reference does (MAX_Q_GEMM_ROWS_8BIT, q_gemm.cu:1707).
+__global__ void gptq8_gather_rows_kernel(uint32_t* __restrict__ dst, const uint32_t* __restrict__ src,
+                                         const int32_t* __restrict__ q_perm, int word_rows, int N) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)word_rows * N) return;
+  const int r = (int)(idx / N), n = (int)(idx - (int64_t)r * N);
+  uint32_t w = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int srow = q_perm[4 * r + i];
+    w |= ((src[(size_t)(srow >> 2) * N + n] >> (8 * (srow & 3))) & 0xffu) << (8 * i);
+  }
+  dst[idx] = w;
+}
+
+// W[k][n] of row k of the (possibly gathered) weight: exact integer difference, one fp16 rounding for the product
+__device__ __forceinline__ _Float16 gptq8_weight(uint32_t word, int i, const uint32_t* __restrict__ qzeros,
+                                                 const uint16_t* __restrict__ scales, int g, int n, int N) {
+  const int zero = (int)((qzeros[(size_t)g * (N / 4) + n / 4] >> (8 * (n & 3))) & 0xffu) + 1;
+  const _Float16 s = __builtin_bit_cast(_Float16, scales[(size_t)g * N + n]);
+  return (_Float16)((_Float16)((int)((word >> (8 * i)) & 0xffu) - zero) * s);
+}
+
+// `rows`: exllama form -- groups are consecutive rows, g_idx (may be NULL) is the row permutation: weight row k is
+// input column / output row g_idx[k]; plain form -- g_idx[k] is the group of row k.
+__global__ void gptq8_dequant_kernel(uint16_t* __restrict__ out, const uint32_t* __restrict__ qweight,
+                                     const uint32_t* __restrict__ qzeros, const uint16_t* __restrict__ scales,
+                                     const int32_t* __restrict__ g_idx, int K, int N, int group_size, int exllama) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)(K / 4) * N) return;
+  const int r = (int)(idx / N), n = (int)(idx - (int64_t)r * N);
+  const uint32_t w = qweight[idx];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int k = 4 * r + i;
+    const int g = exllama ? k / group_size : g_idx[k];
+    const int row = (exllama && g_idx) ? g_idx[k] : k;
+    out[(size_t)row * N + n] = __builtin_bit_cast(uint16_t, gptq8_weight(w, i, qzeros, scales, g, n, N));
+  }
+}
+
+// 64 columns x 4 k-slices per workgroup, up to 8 rows of A per workgroup (grid.y walks the rows)
+__global__ void __launch_bounds__(256)
+gptq8_gemm_kernel(uint16_t* __restrict__ c, const uint16_t* __restrict__ a, const uint32_t* __restrict__ qweight,
+                  const uint32_t* __restrict__ qzeros, const uint16_t* __restrict__ scales,
+                  const int32_t* __restrict__ g_idx, int M, int N, int K, int group_size, int exllama) {
+  __shared__ float red[4][8][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int n = blockIdx.x * 64 + tx;
+  const int m0 = blockIdx.y * 8;
+  const int rows = min(8, M - m0);
+  float acc[8];
+#pragma unroll
+  for (int m = 0; m < 8; ++m) acc[m] = 0.f;
+  if (n < N) {
+    for (int r = ty; r < K / 4; r += 4) {
+      const uint32_t w = qweight[(size_t)r * N + n];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int k = 4 * r + i;
+        const int g = exllama ? k / group_size : g_idx[k];
+        const int col = (exllama && g_idx) ? g_idx[k] : k;
+        const float wv = (float)gptq8_weight(w, i, qzeros, scales, g, n, N);
+        for (int m = 0; m < rows; ++m) acc[m] += f16_bits_to_float(a[(size_t)(m0 + m) * K + col]) * wv;
+      }
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < 8; ++m) red[ty][m][tx] = acc[m];
+  __syncthreads();
+  if (n < N)
+    for (int m = ty; m < rows; m += 4) {
+      const float v = red[0][m][tx] + red[1][m][tx] + red[2][m][tx] + red[3][m][tx];
+      c[(size_t)(m0 + m) * N + n] = float_to_f16_bits(v);
+    }
+}
+
 // ------------------------------------------------------------------ AWQ
 // A word holds 8 output columns of one input row; masking pairs nibbles (0,4) (1,5) (2,6) (3,7),
 // and checkpoints are packed so that those pairs ARE logical columns (0,1) (2,3) (4,5) (6,7)
@@ -1183,7 +1265,19 @@ int64_t sw_quant_gemm_workspace_bytes(int M, int N, int K) {
 }
 
 int sw_gptq_shuffle(uint32_t* qweight, const int32_t* q_perm, int K, int N, int bit, void* scratch, void* stream) {
-  SW_CHECK_ARG(bit == 4, "gptq_shuffle: only 4-bit weights are supported (got %d)", bit);
+  if (bit == 8) {                                     // the 8-bit word order is the checkpoint's; only rows may move
+    SW_CHECK_ARG(K > 0 && N > 0 && K % 4 == 0, "gptq_shuffle: bad shape K=%d N=%d", K, N);
+    if (q_perm == nullptr) return SW_OK;
+    SW_CHECK_ARG(scratch != nullptr, "gptq_shuffle: a row permutation needs a scratch buffer");
+    hipStream_t st8 = static_cast<hipStream_t>(stream);
+    const int64_t words8 = (int64_t)(K / 4) * N;
+    hipLaunchKernelGGL(gptq8_gather_rows_kernel, dim3((unsigned)((words8 + 255) / 256)), dim3(256), 0, st8,
+                       static_cast<uint32_t*>(scratch), qweight, q_perm, K / 4, N);
+    SW_CHECK_LAUNCH();
+    SW_CHECK_HIP(hipMemcpyAsync(qweight, scratch, words8 * 4, hipMemcpyDeviceToDevice, st8));
+    return SW_OK;
+  }
+  SW_CHECK_ARG(bit == 4, "gptq_shuffle: only 4-bit and 8-bit weights are supported (got %d)", bit);
   SW_CHECK_ARG(K > 0 && N > 0 && K % 8 == 0, "gptq_shuffle: bad shape K=%d N=%d", K, N);
   SW_CHECK_ARG(q_perm == nullptr || scratch != nullptr, "gptq_shuffle: a row permutation needs a scratch buffer");
   hipStream_t st = static_cast<hipStream_t>(stream);
@@ -1204,7 +1298,18 @@ int sw_gptq_shuffle(uint32_t* qweight, const int32_t* q_perm, int K, int N, int 
 static int kmajor_dequant(void* out, const uint32_t* qweight, const uint32_t* qzeros, const void* scales,
                           const int32_t* g_idx, int K, int N, int groups, int use_exllama, int bit, int zoff,
                           void* stream) {
-  SW_CHECK_ARG(bit == 4, "gptq_dequant: only 4-bit weights are supported (got %d)", bit);
+  if (bit == 8 && zoff == 1) {
+    SW_CHECK_ARG(K > 0 && N > 0 && groups > 0 && K % 4 == 0 && N % 4 == 0 && K % groups == 0,
+                 "gptq_dequant: bad shape K=%d N=%d groups=%d", K, N, groups);
+    SW_CHECK_ARG(use_exllama || g_idx != nullptr, "gptq_dequant: plain weights need g_idx");
+    const int64_t words8 = (int64_t)(K / 4) * N;
+    hipLaunchKernelGGL(gptq8_dequant_kernel, dim3((unsigned)((words8 + 255) / 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), static_cast<uint16_t*>(out), qweight, qzeros,
+                       static_cast<const uint16_t*>(scales), g_idx, K, N, K / groups, use_exllama ? 1 : 0);
+    SW_CHECK_LAUNCH();
+    return SW_OK;
+  }
+  SW_CHECK_ARG(bit == 4, "gptq_dequant: only 4-bit and 8-bit weights are supported (got %d)", bit);
   SW_CHECK_ARG(K > 0 && N > 0 && groups > 0 && K % 8 == 0 && N % 8 == 0 && K % groups == 0,
                "gptq_dequant: bad shape K=%d N=%d groups=%d", K, N, groups);
   SW_CHECK_ARG(use_exllama || g_idx != nullptr, "gptq_dequant: plain weights need g_idx");
@@ -1226,7 +1331,19 @@ int sw_gptq_dequant(void* out, const uint32_t* qweight, const uint32_t* qzeros, 
 static int kmajor_gemm(void* c, const void* a, const uint32_t* qweight, const uint32_t* qzeros, const void* scales,
                        const int32_t* g_idx, int M, int N, int K, int groups, int use_exllama, int bit, int zoff,
                        void* workspace, int64_t workspace_bytes, void* stream) {
-  SW_CHECK_ARG(bit == 4, "gptq_gemm: only 4-bit weights are supported (got %d)", bit);
+  if (bit == 8 && zoff == 1) {
+    SW_CHECK_ARG(M >= 0 && N > 0 && K > 0 && groups > 0 && K % 4 == 0 && N % 4 == 0 && K % groups == 0,
+                 "gptq_gemm: bad shape M=%d N=%d K=%d groups=%d", M, N, K, groups);
+    SW_CHECK_ARG(use_exllama || g_idx != nullptr, "gptq_gemm: plain (unshuffled) weights need g_idx");
+    if (M == 0) return SW_OK;
+    hipLaunchKernelGGL(gptq8_gemm_kernel, dim3((N + 63) / 64, (M + 7) / 8), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), static_cast<uint16_t*>(c), static_cast<const uint16_t*>(a),
+                       qweight, qzeros, static_cast<const uint16_t*>(scales), g_idx, M, N, K, K / groups,
+                       use_exllama ? 1 : 0);
+    SW_CHECK_LAUNCH();
+    return SW_OK;
+  }
+  SW_CHECK_ARG(bit == 4, "gptq_gemm: only 4-bit and 8-bit weights are supported (got %d)", bit);
   SW_CHECK_ARG(M >= 0 && N > 0 && K > 0 && groups > 0 && K % 32 == 0 && N % 8 == 0 && K % groups == 0,
                "gptq_gemm: bad shape M=%d N=%d K=%d groups=%d", M, N, K, groups);
   if (M == 0) return SW_OK;

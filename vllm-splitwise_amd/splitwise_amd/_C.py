@@ -675,7 +675,8 @@ def gptq_gemm(a: torch.Tensor, b_q_weight: torch.Tensor, b_gptq_qzeros: torch.Te
     n = b_q_weight.size(1)
     if k != b_q_weight.size(0) * 32 // bit:
         raise RuntimeError(f"gptq_gemm: input has {k} columns, weight has {b_q_weight.size(0) * 32 // bit} rows")
-    if m > GPTQ_FUSED_MAX_ROWS:
+    # 8-bit weights: reconstruction + dense GEMM above 24 rows, as the reference (MAX_Q_GEMM_ROWS_8BIT, q_gemm.cu:1707)
+    if m > (GPTQ_FUSED_MAX_ROWS if bit != 8 else 24):
         return torch.matmul(a, gptq_dequant(b_q_weight, b_gptq_qzeros, b_gptq_scales, b_g_idx, bit, use_exllama))
     idx = _optional_index(b_g_idx)
     c = torch.empty((m, n), dtype=torch.float16, device=a.device)

@@ -1,6 +1,6 @@
 """GPTQ linear layers (vllm/model_executor/layers/quantization/gptq.py:18-222).
 
-4-bit only: the native library provides no 2/3/8-bit kernels.  Parameter shapes, the lazy
+4-bit (matrix-core kernels) and 8-bit (plain kernels): the native library provides no 2/3-bit kernels.  Parameter shapes, the lazy
 shuffle on the first forward pass and the act-order rules are the reference's.
 """
 import enum
@@ -23,8 +23,8 @@ class GPTQConfig(QuantizationConfig):
         if weight_bits not in (2, 3, 4, 8):
             raise ValueError("Currently, only 2/3/4/8-bit weight quantization is supported for GPTQ, but got "
                              f"{weight_bits} bits.")
-        if weight_bits != 4:
-            raise ValueError(f"this build provides 4-bit GPTQ kernels only, got {weight_bits} bits")
+        if weight_bits not in (4, 8):
+            raise ValueError(f"this build provides 4-bit and 8-bit GPTQ kernels only, got {weight_bits} bits")
         self.pack_factor = 32 // weight_bits
 
     def __repr__(self) -> str:
@@ -113,7 +113,8 @@ class GPTQLinearMethod(LinearMethodBase):
             _C.ops.gptq_shuffle(weights["qweight"], weights["g_idx"], self.quant_config.weight_bits)
         ready = weights["exllama_state"] == ExllamaState.READY
         dense = None
-        if reshaped_x.shape[0] > _C.GPTQ_FUSED_MAX_ROWS and reshaped_x.is_cuda:
+        fused_rows = 24 if self.quant_config.weight_bits == 8 else _C.GPTQ_FUSED_MAX_ROWS     # q_gemm.cu:1707
+        if reshaped_x.shape[0] > fused_rows and reshaped_x.is_cuda:
             # many rows: reconstruct + dense GEMM, as ops.gptq_gemm does -- with the reconstruction kept
             dense = dense_weight(weights, reshaped_x.shape[-1], qweight.shape[-1],
                                  lambda: _C.ops.dequant_gptq(weights["qweight"], weights["qzeros"], weights["scales"],
