@@ -79,6 +79,15 @@ paged_attention_mfma_kernel(void* __restrict__ out_, float* __restrict__ exp_sum
   using MM = PaMfma<F16M>;
   constexpr int CS = FP8 ? 1 : 2;
   constexpr int KS = HEAD / 32;            // k steps of Q.K
+  // An fp8 cache holds 16 cache elements in its 16-byte pieces where a 16-bit cache holds 8, so a lane that takes
+  // "its 8 elements" of a k step loads 8 bytes: half the bytes in flight per load instruction, which is what bounds
+  // small launches.  A matrix product does not care in which order the contraction index is walked as long as both
+  // operands agree, so with WIDE the lane takes a whole 16-byte piece -- 16 head elements of a key (two k steps'
+  // worth for this lane), 16 tokens of a value row -- and the OTHER operand (q fragments from global memory, P
+  // fragments from the strip) is addressed to match:
+  //   Q.K   step 2 m + h, slot (kq, j)  <->  head element 64 m + 16 kq + 8 h + j      (not 32 ks + 8 kq + j)
+  //   P.V   step p,       slot (kq, j)  <->  token g_tok0 + 16 kq + 8 p + j           (not g_tok0 + 32 p + 8 kq + j)
+  constexpr bool WIDE = FP8 && HEAD % 64 == 0;
   constexpr int DT = HEAD / 16;            // 16-dim tiles of O^T
   static_assert(HEAD % 32 == 0 && (BS == 16 || BS == 32), "head size / block size of the matrix-core decode kernel");
 
@@ -129,11 +138,12 @@ paged_attention_mfma_kernel(void* __restrict__ out_, float* __restrict__ exp_sum
   pa_u32x4 qf[KS];
   float head_scale = scale;                // softmax scale of the lane's head column
   {
-    const S* q = reinterpret_cast<const S*>(q_) + seq * q_stride + (int64_t)(head0 + r) * HEAD + 8 * kq;
+    const S* q = reinterpret_cast<const S*>(q_) + seq * q_stride + (int64_t)(head0 + r) * HEAD;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       pa_u32x4 v = {0u, 0u, 0u, 0u};
-      if (r < qg) v = *reinterpret_cast<const pa_u32x4*>(q + 32 * ks);
+      const int d0 = WIDE ? 64 * (ks >> 1) + 16 * kq + 8 * (ks & 1) : 32 * ks + 8 * kq;
+      if (r < qg) v = *reinterpret_cast<const pa_u32x4*>(q + d0);
       qf[ks] = v;
     }
     if constexpr (REEXPRESS) {
@@ -189,18 +199,52 @@ paged_attention_mfma_kernel(void* __restrict__ out_, float* __restrict__ exp_sum
       const int bidx = min(token / BS, num_ctx_blocks - 1);               // keep the table read in range
       const char* kp = k_cache + (int64_t)block_table[bidx] * block_bytes + head_off;
       const int off = token % BS;
+      if constexpr (WIDE) {                  // [HEAD/16][BS][16] bytes: a whole piece = this lane's slots of two k steps
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        if constexpr (FP8) {                 // [HEAD/16][BS][16] bytes: the lane's 8 dims are half a 16-byte piece
-          const uint2 w = *reinterpret_cast<const uint2*>(kp + ((2 * ks + (kq >> 1)) * BS + off) * 16 + 8 * (kq & 1));
-          kf[t][ks] = e5m2x8_to_f16x8(w.x, w.y);
-        } else {                             // [HEAD/8][BS][8] 16-bit elements
-          kf[t][ks] = *reinterpret_cast<const pa_u32x4*>(kp + ((4 * ks + kq) * BS + off) * 16);
+        for (int m = 0; m < KS / 2; ++m) {
+          const pa_u32x4 w = *reinterpret_cast<const pa_u32x4*>(kp + ((4 * m + kq) * BS + off) * 16);
+          kf[t][2 * m] = e5m2x8_to_f16x8(w[0], w[1]);
+          kf[t][2 * m + 1] = e5m2x8_to_f16x8(w[2], w[3]);
+        }
+      } else {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          if constexpr (FP8) {               // the lane's 8 dims are half a 16-byte piece
+            const uint2 w = *reinterpret_cast<const uint2*>(kp + ((2 * ks + (kq >> 1)) * BS + off) * 16 + 8 * (kq & 1));
+            kf[t][ks] = e5m2x8_to_f16x8(w.x, w.y);
+          } else {                           // [HEAD/8][BS][8] 16-bit elements
+            kf[t][ks] = *reinterpret_cast<const pa_u32x4*>(kp + ((4 * ks + kq) * BS + off) * 16);
+          }
         }
       }
     }
-    // value fragment (half p, dim tile dt): dim 16 dt + r, tokens g_tok0 + 32 p + 8 kq ..+7
+    // value fragment (step p, dim tile dt): dim 16 dt + r, tokens g_tok0 + 32 p + 8 kq ..+7
+    // (WIDE: tokens g_tok0 + 16 kq + 8 p ..+7 -- one 16-byte load brings both steps' tokens)
     pa_u32x4 vf[2][DT];
+    if constexpr (WIDE) {
+      const int token = g_tok0 + 16 * kq;
+      const int bidx = min(token / BS, num_ctx_blocks - 1);
+      const char* vp = v_cache + (int64_t)block_table[bidx] * block_bytes + head_off + (token % BS);
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        const pa_u32x4 w = *reinterpret_cast<const pa_u32x4*>(vp + (16 * dt + r) * BS);
+        vf[0][dt] = e5m2x8_to_f16x8(w[0], w[1]);
+        vf[1][dt] = e5m2x8_to_f16x8(w[2], w[3]);
+      }
+      if (g_tok0 + 64 > ctx) {
+        // tokens past the context may hold anything, NaNs included, and 0 x NaN is NaN: clear them
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          const int live = ctx - (token + 8 * p);                             // elements 0 .. live-1 are real
+#pragma unroll
+          for (int w = 0; w < 4; ++w) {
+            const uint32_t mask = (2 * w < live ? 0x0000ffffu : 0u) | (2 * w + 1 < live ? 0xffff0000u : 0u);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) vf[p][dt][w] &= mask;
+          }
+        }
+      }
+    } else {
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
       const int token = g_tok0 + 32 * p + 8 * kq;
@@ -225,6 +269,7 @@ paged_attention_mfma_kernel(void* __restrict__ out_, float* __restrict__ exp_sum
           for (int dt = 0; dt < DT; ++dt) vf[p][dt][w] &= mask;
         }
       }
+    }
     }
 
     // ---------------------------------------------------------------- Q.K
@@ -281,8 +326,9 @@ paged_attention_mfma_kernel(void* __restrict__ out_, float* __restrict__ exp_sum
     // ---------------------------------------------------------------- P.V
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
-      if (g_tok0 + 32 * p >= tok_end) break;                                // wave-uniform
-      const pa_u32x4 pf = *reinterpret_cast<const pa_u32x4*>(p_w + r * kPaMfmaPRow + 32 * p + 8 * kq);
+      if (!WIDE && g_tok0 + 32 * p >= tok_end) break;                       // wave-uniform (WIDE: a step spans the group)
+      const pa_u32x4 pf =
+          *reinterpret_cast<const pa_u32x4*>(p_w + r * kPaMfmaPRow + (WIDE ? 16 * kq + 8 * p : 32 * p + 8 * kq));
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) acc[dt] = MM::run(vf[p][dt], pf, acc[dt]);
     }

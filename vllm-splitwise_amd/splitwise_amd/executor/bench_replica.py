@@ -67,7 +67,11 @@ def build_engine(spec: Dict[str, Any]):
         num_gpu_blocks_override=max(int(conc * seq_blocks * 1.25) + 64, 2048 // 16 + 8), swap_space=0.25,
         enforce_eager=spec.get("enforce_eager", False), max_context_len_to_capture=1024,
         prefill_batch_tokens=spec["prefill_batch_tokens"], prefill_max_wait=spec["prefill_max_wait"],
-        pipeline_steps=spec.get("pipeline_steps", True), token_pools=spec.get("token_pools", 1))
+        pipeline_steps=spec.get("pipeline_steps", True), token_pools=spec.get("token_pools", 1),
+        # a prompt pool keeps only the prompts in flight (the reference's same-numbering layout would hold a second
+        # full cache on the prompt GPUs for nothing); SPLITWISE_BENCH_REFERENCE_LAYOUT=1 measures that layout
+        staged_prompt_cache=split and spec.get("pipeline_steps", True)
+        and os.environ.get("SPLITWISE_BENCH_REFERENCE_LAYOUT") != "1")
     mc, cc, pc, sc, dc = args.create_engine_configs()
     devices = list(spec["devices"])
     if len(devices) != pc.world_size:
