@@ -90,13 +90,15 @@ def build_plan(n: int, model: str = "llama-2-7b", dtype: str = "bfloat16", legs:
                      "replicas": _trios_layout(n, model, dtype, **base)})
     q13 = dict(quantization="gptq", kv_cache_dtype="fp8_e5m2")
     if n == 4:
+        # (the tensor-parallel leg last: should a pool hang on its first run over real links, the legs before it
+        # have their numbers)
         plan += [
-            {"name": "13b_gptq_fp8_tp2_pools", "role": "config",
-             "replicas": [_replica("split", [0, 1, 2, 3], "llama-2-13b", "float16", tp=2, **q13)]},
             {"name": "13b_gptq_fp8_pairs", "role": "config",
              "replicas": _pairs_layout(4, "llama-2-13b", "float16", **q13)},
             {"name": "13b_gptq_fp8_colocated", "role": "colocated", "of": "13b_gptq_fp8_tp2_pools",
              "replicas": [_replica("colocated", [i], "llama-2-13b", "float16", **q13) for i in range(4)]},
+            {"name": "13b_gptq_fp8_tp2_pools", "role": "config",
+             "replicas": [_replica("split", [0, 1, 2, 3], "llama-2-13b", "float16", tp=2, **q13)]},
         ]
     if n == 8:
         plan += [
@@ -308,7 +310,7 @@ def main(args) -> int:
                 import shutil
                 os.makedirs(keep, exist_ok=True)
                 for name in os.listdir(workdir):
-                    if name.endswith(".log"):
+                    if name.endswith(".log") or name.endswith(".json"):
                         shutil.copy(os.path.join(workdir, name), os.path.join(keep, name))
     return emit()
 
