@@ -197,8 +197,11 @@ def _run(spec: Dict[str, Any]) -> None:
     t0 = time.perf_counter()
     ctx_samples: List[List[int]] = []
     stride = max(1, steps // 12)
+    step_ms: List[float] = []
     for i in range(steps):
+        t_step = time.perf_counter()
         loop.step(True)
+        step_ms.append(round((time.perf_counter() - t_step) * 1e3, 3))
         if i % stride == stride // 2 and len(ctx_samples) < 12:      # decode batches of the timed region
             lens = _running_context_lens(engine)
             if lens:
@@ -225,7 +228,10 @@ def _run(spec: Dict[str, Any]) -> None:
         "pipelined": bool(getattr(engine, "pipeline_split", False) or getattr(engine, "pipeline_steps", False)),
         "kv_bytes_pushed": int(executor.kv_bytes_pushed()) if hasattr(executor, "kv_bytes_pushed") else 0,
         "kv_migration": None, "roofline": None,
+        "step_ms_max": max(step_ms) if step_ms else None,      # host time of the slowest engine call
     }
+    if verbose:
+        result["step_ms"] = step_ms
     # the probes come after the measurement and must never cost it: a probe that fails is reported as such
     try:
         if on_gpu and spec["kind"] == "split":
