@@ -3,6 +3,7 @@ decode) against the whole-model CPU oracle, greedy decoding on small seeded-rand
 Llama and OPT geometry (the offline flow of examples/offline_inference.py and
 tests/basic_correctness/test_basic_correctness.py, with local random weights: no hub access)."""
 import random
+import types
 
 import pytest
 import torch
@@ -365,12 +366,21 @@ def test_parallel_sampling_forks_share_the_prompt_and_copy_on_write(pipeline, bl
                 done[out.request_id] = out
         steps += 1
         assert steps < 5000
+    def same_or_near_tie(i, got):
+        # A sequence that was preempted is recomputed as one long prompt: its keys and values then come from the
+        # prompt kernels, whose sums run in another order than the decode step's, and the random-weight model has
+        # near-ties.  A token that differs from the unpreempted run must still be the CPU model's choice within the
+        # tolerance of the other greedy tests.
+        if got.token_ids != want[i]:
+            _check_greedy(llm, [prompts[i]], [types.SimpleNamespace(outputs=[got])], 3e-2)
+
     for i in range(len(prompts)):
         out = done[f"f{i}"]
         assert [c.index for c in out.outputs] == [0, 1, 2]
         for c in out.outputs:
-            assert c.token_ids == want[i] and c.finish_reason == "length", (i, c.index)
-        assert done[f"g{i}"].outputs[0].token_ids == want[i]
+            assert len(c.token_ids) == 24 and c.finish_reason == "length", (i, c.index)
+            same_or_near_tie(i, c)
+        same_or_near_tie(i, done[f"g{i}"].outputs[0])
     assert not engine._multi_sample_requests
     assert engine.scheduler.block_manager.get_num_free_gpu_blocks() == blocks          # every fork's blocks came back
     if blocks == 24:

@@ -128,6 +128,27 @@ def test_seeded_random_ragged_launches(seed):
     torch.testing.assert_close(out.cpu().float(), ref.float(), atol=1e-3, rtol=1e-5)
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("variant", ["plain", "alibi", "window"])
+@pytest.mark.parametrize("seq_lens", [[772], [772, 772], [4], [65, 130]])
+def test_both_sides_of_the_paired_waves_rule(dtype, variant, seq_lens):
+    """A launch of at most 256 workgroups of 128 rows (one 772-token prompt of 32 heads is 224) runs pairs of waves
+    that share 32 query rows and split every stage's keys, joined through LDS at the end; two such prompts (448) run
+    the plain form.  Same oracle, same tolerance, on both sides of the rule."""
+    torch.manual_seed(3)
+    h, kvh, d = 32, 8, 128
+    n = sum(seq_lens)
+    scale = float(d ** -0.5)
+    qkv = torch.empty(n, h + 2 * kvh, d, dtype=dtype).uniform_(-scale, scale)
+    q, k, v = qkv.split([h, kvh, kvh], dim=1)
+    alibi = torch.randn(h, dtype=torch.float) * 0.05 if variant == "alibi" else None
+    window = 200 if variant == "window" else None
+    ref = oattn.prefill_attention(q, k, v, seq_lens, scale, alibi, window)
+    qd, kd, vd = qkv.cuda().split([h, kvh, kvh], dim=1)
+    out = run(qd, kd, vd, seq_lens, scale, alibi.cuda() if alibi is not None else None, window=window)
+    torch.testing.assert_close(out.cpu().float(), ref.float(), atol=1e-3, rtol=1e-5)
+
+
 def test_float32_is_rejected():
     from splitwise_amd import _C
     q = torch.zeros(4, 2, 64, device="cuda")

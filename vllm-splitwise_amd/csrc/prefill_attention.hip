@@ -30,6 +30,9 @@
 //     is rescaled only when some lane's running maximum has grown by more than 2^8.
 //   * a cached prefix (sw_context_attention) is handled before the causal part, its K and V^T
 //     fragments loaded straight from the paged cache layouts.
+//   * launches of less than one workgroup per CU (KSW = 2): the workgroup's waves are pairs that share 32 query rows
+//     and take one score tile of every stage each, then join their (maximum, sum, output) through LDS: half as many
+//     query rows per workgroup, so twice the workgroups, each wave with half the matrix work of its key loop.
 #include "common.cuh"
 #include <float.h>
 #include <stdlib.h>
@@ -98,7 +101,7 @@ struct PfContext {
   int64_t total_rows;
 };
 
-template <typename act_t, int HEAD, bool CTX, int WAVES>
+template <typename act_t, int HEAD, bool CTX, int WAVES, int KSW>
 __global__ void __launch_bounds__(WAVES * 64, (HEAD <= 128 && WAVES == 4) ? 2 : 1)
 prefill_attention_kernel(uint16_t* __restrict__ out, const uint16_t* __restrict__ q,
                          const uint16_t* __restrict__ k, const uint16_t* __restrict__ v,
@@ -110,6 +113,9 @@ prefill_attention_kernel(uint16_t* __restrict__ out, const uint16_t* __restrict_
   using M = Mfma<act_t>;
   using frag = typename M::frag;
   constexpr int NT = pf_tiles(HEAD);                 // score tiles per stage
+  constexpr int NTW = NT / KSW;                      // ... of which a wave takes this many
+  constexpr int RG = WAVES / KSW;                    // groups of 32 query rows per workgroup
+  static_assert(NT % KSW == 0 && WAVES % KSW == 0 && (KSW == 1 || KSW == 2), "key split of a stage's score tiles");
   constexpr int kPfStage = NT * kPfKeys;             // keys per stage
   constexpr int KS = HEAD / 16;                      // k-steps of the Q.K product
   constexpr int DP = pf_dp(HEAD);
@@ -147,12 +153,13 @@ prefill_attention_kernel(uint16_t* __restrict__ out, const uint16_t* __restrict_
   // Workgroup rank r (0 = first to start) holds, of every sequence, the tile whose end is r tiles before the end of
   // the LONGEST sequence of the launch: a short sequence's tiles start when the long ones' tiles of the same key
   // count do, so that ragged launches too begin with their heaviest tiles.
-  const int tile_e = tile_rank - (max_seq_len - seq_len) / (WAVES * kPfRows);
+  const int tile_e = tile_rank - (max_seq_len - seq_len) / (RG * kPfRows);
   if (tile_e < 0) return;                            // workgroup-uniform
-  const int q_end = seq_len - tile_e * WAVES * kPfRows;
+  const int q_end = seq_len - tile_e * RG * kPfRows;
   if (q_end <= 0) return;                            // workgroup-uniform
-  const int q_base = max(0, q_end - WAVES * kPfRows);
-  const int q0 = q_base + wave * kPfRows;
+  const int q_base = max(0, q_end - RG * kPfRows);
+  const int kw = wave % KSW;                         // which of a stage's tiles this wave takes (tiles kw * NTW ..)
+  const int q0 = q_base + (wave / KSW) * kPfRows;
   const bool active = q0 < q_end;                    // wave-uniform; idle waves still load tiles and meet barriers
   const int64_t row0 = seq_starts[seq];
   const int kv_head = head / (num_heads / num_kv_heads);
@@ -213,18 +220,18 @@ prefill_attention_kernel(uint16_t* __restrict__ out, const uint16_t* __restrict_
   // instructions is pinned: kQkAhead fragments are requested before the first product and one more after each
   // product, so that a product never waits for a read issued just before it.
   auto qk_stage = [&](const char* kb, f32x16* sv) {
-    constexpr int NF = NT * KS;
+    constexpr int NF = NTW * KS;
     constexpr int AHEAD = NF < kQkAhead ? NF : kQkAhead;
     frag kf[NF];
 #pragma unroll
     for (int i = 0; i < NF; ++i)
-      kf[i] = *reinterpret_cast<const frag*>(kb + (i % NT) * kPfKeys * KSTRIDE + 32 * (i / NT));
+      kf[i] = *reinterpret_cast<const frag*>(kb + (i % NTW) * kPfKeys * KSTRIDE + 32 * (i / NTW));
 #pragma unroll
-    for (int u = 0; u < NT; ++u)
+    for (int u = 0; u < NTW; ++u)
 #pragma unroll
       for (int r = 0; r < 16; ++r) sv[u][r] = 0.f;
 #pragma unroll
-    for (int i = 0; i < NF; ++i) sv[i % NT] = M::run(kf[i], qf[i / NT], sv[i % NT]);
+    for (int i = 0; i < NF; ++i) sv[i % NTW] = M::run(kf[i], qf[i / NTW], sv[i % NTW]);
     __builtin_amdgcn_sched_group_barrier(0x100, AHEAD, 0);
 #pragma unroll
     for (int i = 0; i < NF - AHEAD; ++i) {
@@ -378,14 +385,14 @@ prefill_attention_kernel(uint16_t* __restrict__ out, const uint16_t* __restrict_
       // (wave-uniform) this wave's window may begin after the stage
       const bool wanted = active && (sliding_window <= 0 || k0 + kPfStage > ctx + q0 - sliding_window + 1);
       if (wanted) {
-        const char* kb = k_img + cbuf * kPfStage * KSTRIDE + col * KSTRIDE + half * 16;
-        const char* vt = v_img + cbuf * kPfStage * VSTRIDE + col * VTS + 8 * half;
-        f32x16 sv[NT];
+        const char* kb = k_img + (cbuf * kPfStage + kw * NTW * kPfKeys) * KSTRIDE + col * KSTRIDE + half * 16;
+        const char* vt = v_img + cbuf * kPfStage * VSTRIDE + col * VTS + 8 * half + kw * NTW * kPfKeys * 2;
+        f32x16 sv[NTW];
         qk_stage(kb, sv);
-        float mult[NT];
+        float mult[NTW];
 #pragma unroll
-        for (int u = 0; u < NT; ++u) {
-          const int kt = k0 + u * kPfKeys;
+        for (int u = 0; u < NTW; ++u) {
+          const int kt = k0 + (kw * NTW + u) * kPfKeys;
           mult[u] = scale2;
           if (!(kt + kPfKeys <= ctx && slope == 0.f && sliding_window <= 0)) {   // wave-uniform: something to mask
             mult[u] = 1.f;
@@ -400,11 +407,11 @@ prefill_attention_kernel(uint16_t* __restrict__ out, const uint16_t* __restrict_
             }
           }
         }
-        frag pt[2 * NT];
-        softmax_step(std::integral_constant<int, NT>{}, sv, mult, pt);
+        frag pt[2 * NTW];
+        softmax_step(std::integral_constant<int, NTW>{}, sv, mult, pt);
         // O^T += V^T . P^T; A operand element j <-> key 16*st + 8*(j>>2) + 4*half + (j&3) of the tile
 #pragma unroll
-        for (int u = 0; u < NT; ++u)
+        for (int u = 0; u < NTW; ++u)
 #pragma unroll
           for (int st = 0; st < 2; ++st)
 #pragma unroll
@@ -429,7 +436,8 @@ prefill_attention_kernel(uint16_t* __restrict__ out, const uint16_t* __restrict_
     const int q_abs = ctx + q_idx;
     int c_begin = 0;
     if (sliding_window > 0) c_begin = max(0, (ctx + q0 - sliding_window + 1) / kPfKeys * kPfKeys);
-    for (int k0 = c_begin; k0 < ctx; k0 += kPfKeys) {
+    // (waves in pairs take alternate tiles)
+    for (int k0 = c_begin + kw * kPfKeys; k0 < ctx; k0 += KSW * kPfKeys) {
       f32x16 s;
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[r] = 0.f;
@@ -569,13 +577,13 @@ prefill_attention_kernel(uint16_t* __restrict__ out, const uint16_t* __restrict_
     if (t + 2 < stages) fetch(k0 + 2 * kPfStage);
     bool any = false;                                              // wave-uniform
 #pragma unroll
-    for (int u = 0; u < NT; ++u) any = any || needs(k0 + u * kPfKeys);
+    for (int u = 0; u < NTW; ++u) any = any || needs(k0 + (kw * NTW + u) * kPfKeys);
     if (any) {
       // (a tile this wave does not need -- above the diagonal, outside the window -- is computed and
       // masked: keeping it out would make the fragment registers conditionally assigned, which the
       // compiler answers with scratch memory)
-      const char* kb = k_img + buf * kPfStage * KSTRIDE + k_off;
-      const char* vb = v_img + buf * kPfStage * VSTRIDE + tr_off;
+      const char* kb = k_img + (buf * kPfStage + kw * NTW * kPfKeys) * KSTRIDE + k_off;
+      const char* vb = v_img + (buf * kPfStage + kw * NTW * kPfKeys) * VSTRIDE + tr_off;
       // scale and mask (this lane: query q_idx, keys kt + (r&3) + 8*(r>>2) + 4*half)
       // (returns the tile's multiplier, see softmax_exp)
       auto mask_scale = [&](f32x16& sc, int kt) {
@@ -621,18 +629,46 @@ prefill_attention_kernel(uint16_t* __restrict__ out, const uint16_t* __restrict_
       // beside S_b and exp(b) beside P_a.V with an update per tile -- the rescale between the tiles
       // must then see tile a's products, and the two code arms that takes cost more register copies
       // than the overlap saves: the two waves of a SIMD already fill each other's gaps.)
-      f32x16 sv[NT];
+      f32x16 sv[NTW];
       qk_stage(kb, sv);
-      float mult[NT];
+      float mult[NTW];
 #pragma unroll
-      for (int u = 0; u < NT; ++u) mult[u] = mask_scale(sv[u], k0 + u * kPfKeys);
-      frag pt[2 * NT];
-      softmax_step(std::integral_constant<int, NT>{}, sv, mult, pt);
+      for (int u = 0; u < NTW; ++u) mult[u] = mask_scale(sv[u], k0 + (kw * NTW + u) * kPfKeys);
+      frag pt[2 * NTW];
+      softmax_step(std::integral_constant<int, NTW>{}, sv, mult, pt);
 #pragma unroll
-      for (int u = 0; u < NT; ++u) pv_tile(u, pt + 2 * u);
+      for (int u = 0; u < NTW; ++u) pv_tile(u, pt + 2 * u);
     }
     __syncthreads();
     buf ^= 1;
+  }
+  if constexpr (KSW == 2) {
+    // ---- the two waves of a row group join what they saw of the keys: the odd wave hands its running maximum, sum
+    // and output to the even one through LDS (the K / V images are free: every loop above ends with a barrier)
+    constexpr int XW = DB * 16 + 2;                    // floats per lane
+    static_assert(RG * XW * 64 * 4 <= pf_lds_bytes(HEAD), "the exchange must fit the stage buffers");
+    float* xch = reinterpret_cast<float*>(smem) + (wave / KSW) * XW * 64 + lane;
+    __syncthreads();
+    if (kw == 1) {
+#pragma unroll
+      for (int b = 0; b < DB; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xch[(b * 16 + r) * 64] = o[b][r];
+      xch[DB * 16 * 64] = m_run;
+      xch[(DB * 16 + 1) * 64] = l_part;
+    }
+    __syncthreads();
+    if (kw == 1) return;
+    const float m_other = xch[DB * 16 * 64], l_other = xch[(DB * 16 + 1) * 64];
+    const float m_new = fmaxf(m_run, m_other);
+    const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
+    const float a_own = __builtin_amdgcn_exp2f(m_run - m_safe), a_other = __builtin_amdgcn_exp2f(m_other - m_safe);
+    l_part = l_part * a_own + l_other * a_other;
+#pragma unroll
+    for (int b = 0; b < DB; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[b][r] = o[b][r] * a_own + xch[(b * 16 + r) * 64] * a_other;
+    m_run = m_new;
   }
   if (!active) return;
 
@@ -716,12 +752,12 @@ context_attention_reduce_kernel(uint16_t* __restrict__ out, const float* __restr
   }
 }
 
-template <typename act_t, int HEAD, bool CTX, int WAVES>
+template <typename act_t, int HEAD, bool CTX, int WAVES, int KSW>
 int launch_prefill_w(void* out, const void* q, const void* k, const void* v, const int32_t* seq_starts,
                      const int32_t* seq_lens, int num_seqs, int max_seq_len, int num_heads, int num_kv_heads,
                      float scale, const float* alibi, int64_t q_stride, int64_t k_stride, int64_t v_stride,
                      int64_t out_stride, int sliding_window, const PfContext& cx, hipStream_t stream) {
-  const int rows_per_wg = WAVES * kPfRows;
+  const int rows_per_wg = WAVES / KSW * kPfRows;
   const int q_tiles = (max_seq_len + rows_per_wg - 1) / rows_per_wg;
   SW_CHECK_ARG((int64_t)q_tiles * num_heads * num_seqs < (int64_t)1 << 31, "prefill attention: %d x %d x %d workgroups",
                q_tiles, num_heads, num_seqs);
@@ -731,7 +767,7 @@ int launch_prefill_w(void* out, const void* q, const void* k, const void* v, con
                HEAD, cx.block_size);
   dim3 grid((unsigned)(q_tiles * num_heads * num_seqs), (unsigned)parts);
   const size_t smem = (size_t)pf_lds_bytes(HEAD);
-  auto kern = prefill_attention_kernel<act_t, HEAD, CTX, WAVES>;
+  auto kern = prefill_attention_kernel<act_t, HEAD, CTX, WAVES, KSW>;
 
   if (smem > 64 * 1024)
     SW_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -756,6 +792,11 @@ int launch_prefill_w(void* out, const void* q, const void* k, const void* v, con
 // smaller launches are faster with the narrow workgroups, which leave fewer CUs idle in the last round.
 constexpr int kPfWideFrom = 2048;
 constexpr int kPfWideWorkgroups = 384;
+// Launches that do not even give every CU one workgroup of 128 rows (one short prompt) take waves in pairs (64 rows per
+// workgroup, each wave one of a stage's two score tiles): 1 x 772 tokens 25.9 -> 22.5 us, 772 new on 772 cached 71 -> 65 us.
+// From a few hundred workgroups on the pairs lose (3 x 772: 37.6 -> 46.7 us): a wave with one score tile per stage has
+// one chain of matrix products to hide its softmax behind instead of two, and every stage is staged for half the rows.
+constexpr int kPfPairsUpTo = 256;
 
 template <typename act_t, int HEAD, bool CTX>
 int launch_prefill(void* out, const void* q, const void* k, const void* v, const int32_t* seq_starts,
@@ -764,18 +805,28 @@ int launch_prefill(void* out, const void* q, const void* k, const void* v, const
                    int64_t out_stride, int sliding_window, const PfContext& cx, hipStream_t stream) {
   int wide = !CTX && HEAD <= 128 && max_seq_len >= kPfWideFrom &&
              (int64_t)((max_seq_len + 8 * kPfRows - 1) / (8 * kPfRows)) * num_heads * num_seqs >= kPfWideWorkgroups;
+  // Launches of few workgroups wait for their longest key loop: waves in pairs that split every stage's keys
+  const int64_t narrow_wgs = (int64_t)((max_seq_len + kPfWaves * kPfRows - 1) / (kPfWaves * kPfRows)) * num_heads * num_seqs;
+  int pairs = pf_tiles(HEAD) == 2 && narrow_wgs <= kPfPairsUpTo && (!CTX || cx.num_parts <= 1);
 #ifdef SW_PREFILL_EXPERIMENT
   if (const char* env = getenv("SW_PREFILL_WIDE")) wide = !CTX && HEAD <= 128 && atoi(env) != 0;
+  if (const char* env = getenv("SW_PREFILL_PAIRS")) pairs = pf_tiles(HEAD) == 2 && atoi(env) != 0;
 #endif
   if constexpr (!CTX && HEAD <= 128) {
     if (wide)
-      return launch_prefill_w<act_t, HEAD, CTX, 8>(out, q, k, v, seq_starts, seq_lens, num_seqs, max_seq_len, num_heads,
-                                                   num_kv_heads, scale, alibi, q_stride, k_stride, v_stride, out_stride,
-                                                   sliding_window, cx, stream);
+      return launch_prefill_w<act_t, HEAD, CTX, 8, 1>(out, q, k, v, seq_starts, seq_lens, num_seqs, max_seq_len, num_heads,
+                                                      num_kv_heads, scale, alibi, q_stride, k_stride, v_stride, out_stride,
+                                                      sliding_window, cx, stream);
   }
-  return launch_prefill_w<act_t, HEAD, CTX, kPfWaves>(out, q, k, v, seq_starts, seq_lens, num_seqs, max_seq_len,
-                                                      num_heads, num_kv_heads, scale, alibi, q_stride, k_stride,
-                                                      v_stride, out_stride, sliding_window, cx, stream);
+  if constexpr (pf_tiles(HEAD) == 2) {
+    if (pairs)
+      return launch_prefill_w<act_t, HEAD, CTX, kPfWaves, 2>(out, q, k, v, seq_starts, seq_lens, num_seqs, max_seq_len,
+                                                             num_heads, num_kv_heads, scale, alibi, q_stride, k_stride,
+                                                             v_stride, out_stride, sliding_window, cx, stream);
+  }
+  return launch_prefill_w<act_t, HEAD, CTX, kPfWaves, 1>(out, q, k, v, seq_starts, seq_lens, num_seqs, max_seq_len,
+                                                         num_heads, num_kv_heads, scale, alibi, q_stride, k_stride,
+                                                         v_stride, out_stride, sliding_window, cx, stream);
 }
 
 int prefill_entry(void* out, const void* query, const void* key, const void* value, const int32_t* seq_starts,
