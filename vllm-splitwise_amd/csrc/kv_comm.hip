@@ -40,37 +40,67 @@ using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
 // wave only drains its own store queue before it retires.
 // A workgroup walks the chunks blockIdx.x, blockIdx.x + gridDim.x, ...: the grid may be capped to the
 // few workgroups one xGMI link can keep busy, so that a push running beside a layer's attention (on
-// its own stream) does not park thousands of workgroups on link-bound stores.
+// its own stream) does not park thousands of workgroups on link-bound stores.  With few workgroups every one
+// of them has to keep the link busy by itself: a thread holds a whole chunk's 16 pieces in registers, and the
+// loads of the next chunk are issued BEFORE the stores of this one -- the memory counter retires in issue
+// order, so waiting for those loads then does not wait for this chunk's stores, which get a whole chunk's
+// time to cross the link.
+constexpr int kPushPieces = (int)(kChunkBytes / 16 / kPushThreads);     // 16-byte pieces per thread and chunk
+
 __global__ void __launch_bounds__(kPushThreads)
 kv_push_kernel(char* __restrict__ dst_base, const char* __restrict__ src_base, PushRuns runs, int num_chunks) {
-  int r = 0;
-  for (int chunk = blockIdx.x; chunk < num_chunks; chunk += gridDim.x) {
-  while (r + 1 < runs.num_runs && chunk >= runs.first_chunk[r + 1]) ++r;
-  const int64_t begin = (int64_t)(chunk - runs.first_chunk[r]) * kChunkBytes;
-  const int64_t end = min(begin + kChunkBytes, runs.nbytes[r]);
-  const int nbytes = (int)(end - begin);
-  const uint4* src = reinterpret_cast<const uint4*>(src_base + runs.src_offset[r] + begin);
-  // wave-uniform destination descriptor for this chunk (bounds-checked by the hardware)
-  uint64_t d = reinterpret_cast<uint64_t>(dst_base + runs.offset[r] + begin);
-  const uint32_t d_lo = __builtin_amdgcn_readfirstlane((uint32_t)d);
-  const uint32_t d_hi = __builtin_amdgcn_readfirstlane((uint32_t)(d >> 32));
-  char* d_uniform = reinterpret_cast<char*>(((uint64_t)d_hi << 32) | d_lo);
-  const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(d_uniform, 0, nbytes, 0x00020000);
   constexpr int kAuxSystem = 17;                      // sc0 | sc1
-  const int n = nbytes >> 4;
-  int i = threadIdx.x;
-  for (; i + 3 * kPushThreads < n; i += 4 * kPushThreads) {
-    const uint4 a = src[i], b = src[i + kPushThreads], c = src[i + 2 * kPushThreads], e = src[i + 3 * kPushThreads];
-    __builtin_amdgcn_raw_buffer_store_b128(u32x4{a.x, a.y, a.z, a.w}, rsrc, i * 16, 0, kAuxSystem);
-    __builtin_amdgcn_raw_buffer_store_b128(u32x4{b.x, b.y, b.z, b.w}, rsrc, (i + kPushThreads) * 16, 0, kAuxSystem);
-    __builtin_amdgcn_raw_buffer_store_b128(u32x4{c.x, c.y, c.z, c.w}, rsrc, (i + 2 * kPushThreads) * 16, 0, kAuxSystem);
-    __builtin_amdgcn_raw_buffer_store_b128(u32x4{e.x, e.y, e.z, e.w}, rsrc, (i + 3 * kPushThreads) * 16, 0, kAuxSystem);
+  int chunk = blockIdx.x;
+  if (chunk >= num_chunks) return;                    // workgroup-uniform
+  int r = 0;
+  // wave-uniform descriptors of a chunk's source and destination ranges: pieces past the end of a short chunk
+  // read as zero and are not stored (bounds-checked by the hardware)
+  auto describe = [&](int c, auto& s_rsrc, auto& d_rsrc) {
+    while (r + 1 < runs.num_runs && c >= runs.first_chunk[r + 1]) ++r;
+    const int64_t begin = (int64_t)(c - runs.first_chunk[r]) * kChunkBytes;
+    const int nbytes = (int)(min(begin + kChunkBytes, runs.nbytes[r]) - begin);
+    const uint64_t sa = reinterpret_cast<uint64_t>(src_base + runs.src_offset[r] + begin);
+    const uint64_t da = reinterpret_cast<uint64_t>(dst_base + runs.offset[r] + begin);
+    // (the intrinsic returns a signed int: each half goes through an unsigned 32-bit value, or a low half with its
+    // top bit set would sign-extend over the high half)
+    const uint32_t s_lo = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)sa);
+    const uint32_t s_hi = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(sa >> 32));
+    const uint32_t d_lo = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)da);
+    const uint32_t d_hi = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(da >> 32));
+    const uint64_t su = ((uint64_t)s_hi << 32) | (uint64_t)s_lo;
+    const uint64_t du = ((uint64_t)d_hi << 32) | (uint64_t)d_lo;
+    s_rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(su), 0, nbytes, 0x00020000);
+    d_rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(du), 0, nbytes, 0x00020000);
+  };
+  using rsrc_t = decltype(__builtin_amdgcn_make_buffer_rsrc(static_cast<char*>(nullptr), 0, 0, 0));
+  rsrc_t s_cur, d_cur, s_next, d_next;
+  u32x4 cur[kPushPieces], next[kPushPieces];
+  const int lane_off = threadIdx.x * 16;
+  describe(chunk, s_cur, d_cur);
+#pragma unroll
+  for (int i = 0; i < kPushPieces; ++i)
+    cur[i] = __builtin_amdgcn_raw_buffer_load_b128(s_cur, lane_off + i * kPushThreads * 16, 0, 0);
+  // (the last chunk's stores are code of their own: at a point that both "more loads were issued" and "none were"
+  // reach, the compiler's wait-count bookkeeping has to assume the worse of the two and would make every store
+  // wait for the previous chunk's stores)
+  for (;;) {
+    const int following = chunk + gridDim.x;
+    if (following >= num_chunks) break;               // workgroup-uniform
+    describe(following, s_next, d_next);
+#pragma unroll
+    for (int i = 0; i < kPushPieces; ++i)
+      next[i] = __builtin_amdgcn_raw_buffer_load_b128(s_next, lane_off + i * kPushThreads * 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < kPushPieces; ++i)
+      __builtin_amdgcn_raw_buffer_store_b128(cur[i], d_cur, lane_off + i * kPushThreads * 16, 0, kAuxSystem);
+#pragma unroll
+    for (int i = 0; i < kPushPieces; ++i) cur[i] = next[i];
+    d_cur = d_next;
+    chunk = following;
   }
-  for (; i < n; i += kPushThreads) {
-    const uint4 a = src[i];
-    __builtin_amdgcn_raw_buffer_store_b128(u32x4{a.x, a.y, a.z, a.w}, rsrc, i * 16, 0, kAuxSystem);
-  }
-  }
+#pragma unroll
+  for (int i = 0; i < kPushPieces; ++i)
+    __builtin_amdgcn_raw_buffer_store_b128(cur[i], d_cur, lane_off + i * kPushThreads * 16, 0, kAuxSystem);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
