@@ -4,6 +4,13 @@ messages only (step commands, sampled tokens, IPC handles).  The reference uses 
 from typing import Any
 
 
+def pickled(obj: Any) -> bytes:
+    """The bytes ``PipeChannel.send`` would put on the wire for ``obj``: a command that goes to several ranks is
+    serialised once (``send_pickled``)."""
+    from multiprocessing.reduction import ForkingPickler
+    return bytes(ForkingPickler.dumps(obj))
+
+
 class PipeChannel:
     """A multiprocessing connection (full duplex)."""
 
@@ -12,6 +19,10 @@ class PipeChannel:
 
     def send(self, obj: Any) -> None:
         self.conn.send(obj)
+
+    def send_pickled(self, payload: bytes) -> None:
+        """``send`` of an object serialised beforehand with ``pickled``; the receiver sees no difference."""
+        self.conn.send_bytes(payload)
 
     def recv(self, timeout: float = None) -> Any:
         """Blocks at most ``timeout`` seconds (None: for ever).  A peer that has gone away ends the wait at
