@@ -89,6 +89,11 @@ GEMM_SHAPES = [          # (M, K, N, group)
     # k split across workgroups (few column tiles) and not (many), and the wide-matrix case from 97 rows on
     (129, 512, 136, 64), (256, 1024, 264, 128), (255, 768, 1024, 256), (192, 2560, 320, 64), (250, 1280, 72, 1280),
     (160, 256, 3200, 128), (100, 256, 7680, 128), (200, 256, 16648, 128),
+    # 33..128 rows: tiles of 64 columns whose 8 waves are 8 k parts -- 64-row tiles up to 64 rows (and, with a short
+    # k and few columns, two of them up to 128 rows), 128-row tiles otherwise; k split across workgroups (few
+    # columns, long k) and not
+    (40, 4096, 72, 128), (64, 256, 520, 64), (65, 3328, 72, 128), (100, 4096, 1000, 128), (128, 5120, 520, 64),
+    (96, 512, 16648, 128), (128, 512, 264, 64), (70, 1024, 136, 128), (127, 3072, 8192, 256),
 ]
 
 
@@ -118,6 +123,26 @@ def test_gptq_gemm_tile_kernel_on_seeded_random_shapes():
         w = quant.gptq_shuffle(qweight)
         got = _C.ops.gptq_gemm(_dev(a), _dev(w), _dev(qzeros), _dev(scales), torch.empty((1, 1), device="meta"), True, 4)
         _close(got, quant.gptq_gemm(a, w, qzeros, scales, None, True))
+
+
+def test_gptq_gemm_64_column_tiles_on_seeded_random_shapes():
+    """Shapes drawn at random inside the domain of the 64-column tile kernels (rows 33..128, k in multiples of 256,
+    columns in multiples of 8, groups of 64 / 128 / 256 / all of k), against the CPU restatement; every launch
+    twice, bit for bit the same (the k parts and the k splits are summed in a fixed order)."""
+    from splitwise_amd import _C
+    rng = np.random.default_rng(2025)
+    for case in range(12):
+        m = int(rng.integers(33, 129))
+        k = 256 * int(rng.integers(1, 25))
+        n = 8 * int(rng.integers(1, 300))
+        group = int(rng.choice([g for g in (64, 128, 256, k) if k % g == 0]))
+        qweight, qzeros, scales, _ = _gptq_case(k, n, group, 2000 + case)
+        a = rng.standard_normal((m, k)).astype(np.float16)
+        args = (_dev(a), _dev(quant.gptq_shuffle(qweight)), _dev(qzeros), _dev(scales),
+                torch.empty((1, 1), device="meta"), True, 4)
+        got = _C.ops.gptq_gemm(*args)
+        _close(got, quant.gptq_gemm(a, quant.gptq_shuffle(qweight), qzeros, scales, None, True))
+        assert torch.equal(_C.ops.gptq_gemm(*args), got), (m, k, n, group)
 
 
 @pytest.mark.parametrize("m,k,n,group", [(1, 512, 256, 128), (9, 1024, 520, 64), (48, 512, 128, 32), (70, 512, 136, 128),

@@ -23,7 +23,7 @@ def main():
         qz = torch.randint(-2**31, 2**31 - 1, (k // group, n // 8), dtype=torch.int32, device=dev)
         qw = torch.randint(-2**31, 2**31 - 1, (k // 8, n), dtype=torch.int32, device=dev)
         qwa = torch.randint(-2**31, 2**31 - 1, (k, n // 8), dtype=torch.int32, device=dev)
-        for m in (1, 8, 32, 64, 128, 256):
+        for m in (1, 8, 32, 48, 64, 96, 128, 256):
             a = torch.randn(m, k, device=dev).half()
             nbytes = k * n // 2 + (k // group) * n * 2.5 + m * k * 2 + m * n * 2
             t = graph_time(lambda: _C.ops.gptq_gemm(a, qw, qz, scales, none, True, 4), reps=32)

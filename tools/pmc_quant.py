@@ -12,7 +12,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "vllm-splitwise_amd")]
-SHAPES = [("gptq", 1), ("gptq", 32), ("gptq", 128), ("gptq", 256), ("awq", 32)]
+SHAPES = [("gptq", 1), ("gptq", 32), ("gptq", 64), ("gptq", 128), ("gptq", 256), ("awq", 32)]
 K, N, GROUP, REPS = 5120, 13824, 128, 5
 
 

@@ -58,6 +58,10 @@ int main(int argc, char** argv) {
       {"t128 kq2 ks4", "8", "2", "256", "4", "2"},
       {"t128 kq4 auto", "8", "2", "256", nullptr, "4"},
       {"t128 kq4 ks1", "8", "2", "256", "1", "4"},
+      {"t128 kq8 auto", "8", "2", "256", nullptr, "8"},
+      {"t128 kq8 ks1", "8", "2", "256", "1", "8"},
+      {"t64 kq8 auto", "8", "2", "256", nullptr, "68"},
+      {"t64 kq8 ks1", "8", "2", "256", "1", "68"},
       {"t256 kq2 auto", "8", "2", "256", nullptr, "82"},
       {"t256 kq2 ks1", "8", "2", "256", "1", "82"},
       {"t256 kq4cg1 ks1", "8", "2", "256", "1", "84"},

@@ -581,8 +581,12 @@ gptq_gemm_tile128_kernel(uint16_t* __restrict__ c, const uint16_t* __restrict__ 
   constexpr int SEGS = CHUNK / 8;                     // 16-byte pieces per A row
   constexpr int PPT = BM * SEGS / NT;                 // pieces per thread and chunk
   constexpr int PH = PPT / 2;                         // moved in two halves, at the top and in the middle of a chunk
-  static_assert(PPT % 2 == 0 && BPO >= 1, "tile shape");
-  static_assert(KQ * CG * 32 * 64 * 4 <= NBUF * ABUF, "the A buffers must hold one 32-register block per wave at the end");
+  constexpr bool kAllK = KQ > MT;                     // more k parts than row blocks: the parts meet as in the k-waves kernel
+  static_assert(PPT % 2 == 0 && (BPO >= 1 || (kAllK && CG == 1 && KQ == 8)), "tile shape");
+  static_assert(kAllK || KQ * CG * 32 * 64 * 4 <= NBUF * ABUF,
+                "the A buffers must hold one 32-register block per wave at the end");
+  static_assert(!kAllK || 8 * MT * CP * 8 * 64 * 4 <= NBUF * ABUF,
+                "the A buffers must hold 8 accumulator rows of every wave at the end");
   extern __shared__ __attribute__((aligned(16))) char a_lds[];
   __shared__ int s_last;
   const int tid = threadIdx.x;
@@ -756,6 +760,40 @@ gptq_gemm_tile128_kernel(uint16_t* __restrict__ c, const uint16_t* __restrict__ 
     }
   }
 
+  if constexpr (kAllK) {
+    // ---- 8 k parts, one column group: the parts meet as in the k-waves kernel -- two passes of 8 accumulator rows
+    // through LDS, after which wave w owns accumulator row 8 * pass + w of every row block.
+    float* red = reinterpret_cast<float*>(a_lds);
+    float vals[2 * MT][CP];
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      __syncthreads();
+#pragma unroll
+      for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int cc = 0; cc < CP; ++cc)
+#pragma unroll
+          for (int r8 = 0; r8 < 8; ++r8)
+            red[(((wave * MT + t) * CP + cc) * 8 + r8) * 64 + lane] = acc[t][cc][8 * pass + r8];
+      __syncthreads();
+#pragma unroll
+      for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int cc = 0; cc < CP; ++cc) {
+          float v = 0.f;
+#pragma unroll
+          for (int w = 0; w < 8; ++w) v += red[(((w * MT + t) * CP + cc) * 8 + wave) * 64 + lane];
+          vals[pass * MT + t][cc] = v;
+        }
+    }
+    auto row_of = [&](int i) {                            // i = pass * MT + t, accumulator row r = 8 * pass + wave
+      const int pass = i / MT, t = i % MT;
+      return m0 + 32 * t + 16 * pass + 8 * (wave >> 2) + 4 * half + (wave & 3);
+    };
+    auto val_of = [&](int i, int cc) { return vals[i][cc]; };
+    combine_and_store<CP, 2 * MT>(val_of, row_of, col_ok, ncol, c, M, N, ksplit, partials, counters,
+                                  row_tile * col_tiles + col_tile, split, &s_last);
+  } else {
   // ---- the k parts meet: the wave of k part q keeps row blocks q * BPO .. + BPO - 1 and is sent the other parts'
   // sums of them through LDS, one block per pass.
   // (selects between VALUES of fixed accumulator elements: a branch or a conditional expression between two
@@ -800,6 +838,7 @@ gptq_gemm_tile128_kernel(uint16_t* __restrict__ c, const uint16_t* __restrict__ 
   };
   combine_and_store<CP, 16 * BPO>(val_of, row_of, col_ok, ncol, c, M, N, ksplit, partials, counters,
                                   row_tile * col_tiles + col_tile, split, &s_last);
+  }
 }
 
 // ------------------------------------------------------------------ GPTQ, plain (unshuffled) weights + g_idx
@@ -1378,17 +1417,30 @@ static int kmajor_gemm(void* c, const void* a, const uint32_t* qweight, const ui
   }
   float* partials = reinterpret_cast<float*>(ws + kCounterBytes);
   // Kernel choice, from measurements on the 13B / TP2 matrices (tools/quant_exp.hip):
-  //   * 128-row tile kernel: more than 128 rows, and 97..128 rows of matrices with 7680 columns or more (it needs
-  //     k in multiples of 256 and groups in multiples of 64); its tiles are 128 columns wide, 256 when that keeps
-  //     the launch to one round of workgroups (the 27648-column matrix of an unsharded 13B model at 256 rows);
-  //   * up to 128 rows otherwise: one row tile per workgroup, k split across its waves;
-  //   * 64-row tiled kernel: more than 128 rows of shapes the 128-row kernel does not take.
+  //   * up to 32 rows: one row tile per workgroup, k split across its waves, A straight from memory;
+  //   * tile kernels (A through LDS; they need k in multiples of 256 and groups in multiples of 64):
+  //       33..64 rows    64 x 64 tiles, the 8 waves are 8 k parts of every chunk;
+  //       65..128 rows   128 x 64 tiles of the same form -- a 13824-column matrix is 216 of them, so k is not split
+  //                      across workgroups and no fp32 partial tile goes through memory; with a short k (<= 3072) and
+  //                      few columns two 64-row tiles per column tile, k unsplit, are faster than 128-row tiles whose
+  //                      k is split three ways;
+  //       129.. rows     128 x 128 tiles (2 column groups x 4 k parts), 128 x 256 when that keeps the launch to one
+  //                      round of workgroups (the 27648-column matrix of an unsharded 13B model at 256 rows);
+  //   * shapes the tile kernels do not take: k across waves up to 128 rows, the 64-row tiled kernel above.
   int cp = 2, mt = M > 64 ? 4 : M > 32 ? 2 : 1;
   bool tiled = M > 128 && K % kChunkK == 0 && group_size % 16 == 0;
   int waves = 8, chunk = kChunkK, tiled_mt = 2, force_ks = 0;
-  int t_variant = (K % 256 == 0 && group_size % 64 == 0 && (M > 128 || (M > 96 && N >= 7680))) ? 4 : 0;
-  // more 128 x 128 tiles than CUs: tiles of 128 x 256 (4 column groups x 2 k parts) do it in one round
-  if (t_variant == 4 && (int64_t)((M + 127) / 128) * ((N + 127) / 128) > 256) t_variant = 2;
+  int t_variant = 0;
+  if (K % 256 == 0 && group_size % 64 == 0) {
+    if (M > 128) {
+      t_variant = (int64_t)((M + 127) / 128) * ((N + 127) / 128) > 256 ? 2 : 4;
+    } else if (M > 64) {
+      t_variant = 8;
+      if (K <= 3072 && 2 * ((N + 63) / 64) <= 256) { t_variant = 68; force_ks = 1; }
+    } else if (M > 32) {
+      t_variant = 68;
+    }
+  }
 #ifdef SW_QUANT_EXPERIMENT                                     // tuning builds only: never in the shipped library
   if (const char* env = getenv("SW_QUANT_CP")) cp = atoi(env) == 4 ? 4 : 2;
   if (const char* env = getenv("SW_QUANT_MT")) mt = atoi(env);
@@ -1397,18 +1449,26 @@ static int kmajor_gemm(void* c, const void* a, const uint32_t* qweight, const ui
   if (const char* env = getenv("SW_QUANT_CHUNK")) chunk = atoi(env) == 128 ? 128 : 256;
   if (const char* env = getenv("SW_QUANT_TMT")) tiled_mt = atoi(env);
   if (const char* env = getenv("SW_QUANT_KSPLIT")) force_ks = atoi(env);
-  // 0: off; 2, 4: 128 rows x 8 waves with 2 / 4 k parts; 82, 84: 256 rows x 4 waves with 2 / 4 k parts
+  // 0: off; 2, 4, 8: 128 rows x 8 waves with 2 / 4 / 8 k parts; 68: 64 rows, 8 k parts; 82, 84: 256 rows x 4 waves
   if (const char* env = getenv("SW_QUANT_T128")) t_variant = atoi(env);
 #endif
   if (mt == 3 || mt > 4) mt = 4;
   if (tiled) mt = tiled_mt;
   if (t_variant != 0) {
-    const int t_rows = t_variant > 8 ? 256 : 128, t_kq = t_variant > 8 ? t_variant - 80 : t_variant;
-    const int t_cg = (t_variant > 8 ? 4 : 8) / t_kq;
-    SW_CHECK_ARG((t_kq == 2 || t_kq == 4) && K % (t_kq * 64) == 0 && group_size % 64 == 0,
+    // variant -> rows per tile, k parts, column groups of 64, k per chunk
+    int t_rows = 128, t_kq = 4, t_cg = 2, chunk_k = 256;
+    switch (t_variant) {
+      case 4: break;
+      case 2: t_kq = 2; t_cg = 4; chunk_k = 128; break;
+      case 8: t_kq = 8; t_cg = 1; break;
+      case 68: t_rows = 64; t_kq = 8; t_cg = 1; break;
+      case 82: t_rows = 256; t_kq = 2; t_cg = 2; chunk_k = 128; break;
+      case 84: t_rows = 256; t_kq = 4; t_cg = 1; chunk_k = 128; break;
+      default: SW_CHECK_ARG(false, "gptq_gemm: no 128-row tile variant %d", t_variant);
+    }
+    SW_CHECK_ARG(K % 256 == 0 && group_size % 64 == 0,
                  "gptq_gemm: no 128-row tile variant %d for K=%d, group size %d", t_variant, K, group_size);
     const int rt = (M + t_rows - 1) / t_rows, ct = (N + 64 * t_cg - 1) / (64 * t_cg);
-    const int chunk_k = t_variant == 84 ? 128 : t_kq * 64;
     int ks = pick_ksplit(ct * rt, K / chunk_k, 4, M, N, avail, 1, 256);
     if (force_ks > 0 && force_ks <= K / chunk_k) ks = force_ks;
 #define SW_GPTQ_T128(MT_, KQ_, CG_, SPW_, NB_)                                                                 \
@@ -1422,6 +1482,8 @@ static int kmajor_gemm(void* c, const void* a, const uint32_t* qweight, const ui
   } while (0)
     if (t_variant == 4) SW_GPTQ_T128(4, 4, 2, 4, 2);
     else if (t_variant == 2) SW_GPTQ_T128(4, 2, 4, 4, 3);
+    else if (t_variant == 8) SW_GPTQ_T128(4, 8, 1, 2, 2);
+    else if (t_variant == 68) SW_GPTQ_T128(2, 8, 1, 2, 2);
 #ifdef SW_QUANT_EXPERIMENT
     else if (t_variant == 82) SW_GPTQ_T128(8, 2, 2, 4, 2);
     else if (t_variant == 84) SW_GPTQ_T128(8, 4, 1, 2, 2);
