@@ -62,6 +62,9 @@ int main(int argc, char** argv) {
       {"t128 kq8 ks1", "8", "2", "256", "1", "8"},
       {"t64 kq8 auto", "8", "2", "256", nullptr, "68"},
       {"t64 kq8 ks1", "8", "2", "256", "1", "68"},
+      {"t32 kq8 auto", "8", "2", "256", nullptr, "38"},
+      {"t32 kq8 ks1", "8", "2", "256", "1", "38"},
+      {"t32 kq8 ks2", "8", "2", "256", "2", "38"},
       {"t256 kq2 auto", "8", "2", "256", nullptr, "82"},
       {"t256 kq2 ks1", "8", "2", "256", "1", "82"},
       {"t256 kq4cg1 ks1", "8", "2", "256", "1", "84"},

@@ -1464,6 +1464,7 @@ static int kmajor_gemm(void* c, const void* a, const uint32_t* qweight, const ui
       case 2: t_kq = 2; t_cg = 4; chunk_k = 128; break;
       case 8: t_kq = 8; t_cg = 1; break;
       case 68: t_rows = 64; t_kq = 8; t_cg = 1; break;
+      case 38: t_rows = 32; t_kq = 8; t_cg = 1; break;
       case 82: t_rows = 256; t_kq = 2; t_cg = 2; chunk_k = 128; break;
       case 84: t_rows = 256; t_kq = 4; t_cg = 1; chunk_k = 128; break;
       default: SW_CHECK_ARG(false, "gptq_gemm: no 128-row tile variant %d", t_variant);
@@ -1487,6 +1488,7 @@ static int kmajor_gemm(void* c, const void* a, const uint32_t* qweight, const ui
     else if (t_variant == 8) SW_GPTQ_T128(4, 8, 1, 2, 2);
     else if (t_variant == 68) SW_GPTQ_T128(2, 8, 1, 2, 2);
 #ifdef SW_QUANT_EXPERIMENT
+    else if (t_variant == 38) SW_GPTQ_T128(1, 8, 1, 2, 2);    // 32-row tiles: behind the k-across-waves kernel at every shape
     else if (t_variant == 82) SW_GPTQ_T128(8, 2, 2, 4, 2);
     else if (t_variant == 84) SW_GPTQ_T128(8, 4, 1, 2, 2);
 #endif
