@@ -174,11 +174,17 @@ def test_prefill_attention_properties_at_prompt_size():
     # the first token of every sequence attends to itself only: its output is its own value row
     for st in (0, 772, 1544):
         assert torch.equal(base[st], v[st])
-    # sequences are independent: running one alone gives the same rows bit for bit
+    # sequences are independent: running two of them without the first gives the same rows bit for bit ...
+    pair = torch.empty(1544, H, D, dtype=torch.bfloat16, device="cuda")
+    _C.ops.prefill_attention(pair, q[772:], k[772:], v[772:], starts[:2], ln[:2], 772, s)
+    torch.cuda.synchronize()
+    assert torch.equal(pair, base[772:])
+    # ... and one alone -- a launch of less than one workgroup per CU, whose waves split the keys in pairs and sum in
+    # another order -- the same rows to the last bit or two of the bf16 output
     alone = torch.empty(772, H, D, dtype=torch.bfloat16, device="cuda")
     _C.ops.prefill_attention(alone, q[772:1544], k[772:1544], v[772:1544], starts[:1], ln[:1], 772, s)
     torch.cuda.synchronize()
-    assert torch.equal(alone, base[772:1544])
+    torch.testing.assert_close(alone.float(), base[772:1544].float(), atol=1e-3, rtol=1e-2)
 
 
 @pytest.mark.parametrize("fmt", ["gptq", "awq"])
