@@ -347,8 +347,10 @@ def cpu_baseline(model_name, prompt_len, decode_len):
     """The CPU oracle on a bounded sample of the same workload, scaled to tok/s."""
     from oracle import serving as oserving
     threads = torch.get_num_threads()
-    res = oserving.timed_sample(model_name, prompt_len=prompt_len, decode_len=decode_len, layers=2,
-                                num_requests=2, decode_steps=4, budget_s=25.0)
+    # up to 8 layers (a quarter of the 7B model), four requests: ~10 s of host work, scaled by layers (they are identical)
+    geo_layers = oserving._GEOMETRY[model_name]["layers"]
+    res = oserving.timed_sample(model_name, prompt_len=prompt_len, decode_len=decode_len, layers=min(8, max(2, geo_layers // 4)),
+                                num_requests=4, decode_steps=8, budget_s=25.0)
     return {"value": round(res["tokens_per_s"], 3), "unit": "tok/s", "cores": threads, "kind": "port",
             "sample": res["sample"]}
 
