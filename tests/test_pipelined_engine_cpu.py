@@ -212,14 +212,21 @@ def test_abort_during_a_running_prompt_step_keeps_its_blocks_until_the_step_has_
     # new work arrives and is scheduled while the aborted prompt still runs: it must get other blocks
     engine.add_request("b", None, params, prompt_token_ids=list(range(100, 140)))
     engine.step()
-    assert ex.prompt_pending is pending, "the prompt pool is still busy with the aborted step"
-    assert bm.get_num_free_gpu_blocks() == 5
-    pending.finished = True                                                        # the step ends on the GPU
-    outs = engine.step()                                                           # resolved, dropped; b is launched
+    second = ex.prompt_pending
+    assert second is not pending, "a second prompt step is queued behind the one that still runs"
+    seq_b = [g for g in engine.scheduler.running if g.request_id == "b"][0].get_seqs()[0]
+    blocks_b = set(bm.get_block_table(seq_b))
+    assert len(blocks_b) == 3 and not (blocks_b & blocks_a) and bm.get_num_free_gpu_blocks() == 2
+    # a third prompt has to wait: two prompt steps are in flight
+    engine.add_request("c", None, params, prompt_token_ids=list(range(200, 210)))
+    engine.step()
+    assert ex.prompt_pending is second and bm.get_num_free_gpu_blocks() == 2
+    pending.finished = True                                                        # the first step ends on the GPU
+    outs = engine.step()                                                           # resolved, dropped; c is launched
     assert all(o.request_id != "a" for o in outs)
-    assert ex.prompt_pending is not pending
-    seq_b = engine.scheduler.running[0].get_seqs()[0]
-    assert bm.get_num_free_gpu_blocks() == 8 - len(bm.get_block_table(seq_b))      # a's blocks came back
+    assert ex.prompt_pending is not second
+    assert bm.get_num_free_gpu_blocks() == 8 - 3 - 1                               # a's blocks came back; b and c hold theirs
+    second.finished = True
     ex.prompt_pending.finished = True
     final = {}
     for _ in range(50):
@@ -230,8 +237,11 @@ def test_abort_during_a_running_prompt_step_keeps_its_blocks_until_the_step_has_
             ex.prompt_pending.finished = True
         if not engine.has_unfinished_requests():
             break
-    seq = list(range(100, 140))
-    for _ in range(4):
-        seq.append(next_token(seq))
-    assert final == {"b": seq[40:]}
+    want = {}
+    for rid, prompt in (("b", list(range(100, 140))), ("c", list(range(200, 210)))):
+        seq = list(prompt)
+        for _ in range(4):
+            seq.append(next_token(seq))
+        want[rid] = seq[len(prompt):]
+    assert final == want
     assert bm.get_num_free_gpu_blocks() == 8

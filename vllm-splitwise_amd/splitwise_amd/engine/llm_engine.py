@@ -7,7 +7,8 @@ search and n > 1 forking are outside this build (one sequence per request).
 import gc
 import os
 import time
-from typing import Dict, Iterable, List, Optional, Union
+from collections import deque
+from typing import Deque, Dict, Iterable, List, Optional, Union
 
 from ..config import CacheConfig, DeviceConfig, ModelConfig, ParallelConfig, SchedulerConfig
 from ..core.scheduler import Scheduler, SchedulerGroup, SchedulerOutputs
@@ -77,7 +78,13 @@ class LLMEngine:
         # split pools, pipelined: the prompt pool and the token pool each have a step in flight
         self.pipeline_split = (getattr(scheduler_config, "pipeline_steps", False) and self.overlap_pools
                                and getattr(self.model_executor, "supports_pipelined_split", False))
-        self._prompt_inflight = None    # (pending samples, scheduler outputs, request ids, lane)
+        # prompt steps launched and not resolved yet, oldest first: (pending samples, scheduler outputs, request ids,
+        # lane).  Two deep: the engine looks at the prompt pool once per decode step, so with one step in flight the
+        # pool would sit idle from the end of a prompt step to the next look (a prompt GPU that feeds two token GPUs has
+        # no such time to give away); the second step waits on the device, in stream order.  A staged prompt cache has
+        # room for exactly two steps.
+        self._prompt_queue: Deque[tuple] = deque()
+        self._prompt_queue_depth = 2
         self._decode_inflight: List[Optional[tuple]] = [None] * lanes   # per lane: (scheduler outputs, [(group, sequence)])
         self._free_later: List[List[Sequence]] = [[] for _ in range(lanes)]
         # requests with best_of > 1 that are alive: while there are any, a pipelined engine runs plain steps (a
@@ -101,8 +108,8 @@ class LLMEngine:
     def _seq_in_flight(self, seq: Sequence) -> bool:
         """Pipelined split pools: is the sequence part of a prompt step or a decode step that has been
         launched and not resolved yet?"""
-        if self._prompt_inflight is not None:
-            for group in self._prompt_inflight[1].scheduled_seq_groups:
+        for entry in self._prompt_queue:
+            for group in entry[1].scheduled_seq_groups:
                 if any(s.seq_id == seq.seq_id for s in group.get_seqs()):
                     return True
         for inflight in self._decode_inflight:
@@ -119,8 +126,8 @@ class LLMEngine:
         for inflight in self._decode_inflight:
             if inflight is not None:
                 ids += [group.request_id for group, _ in inflight[1]]
-        if self._prompt_inflight is not None:
-            ids += list(self._prompt_inflight[2])
+        for entry in self._prompt_queue:
+            ids += list(entry[2])
         return ids
 
     @classmethod
@@ -161,7 +168,7 @@ class LLMEngine:
 
     def has_unfinished_requests(self) -> bool:
         return (self.scheduler.has_unfinished_seqs() or self._inflight is not None
-                or self._prompt_inflight is not None or any(d is not None for d in self._decode_inflight)
+                or bool(self._prompt_queue) or any(d is not None for d in self._decode_inflight)
                 or any(self._free_later) or bool(self.scheduler.held_after_abort))
 
     # --------------------------------------------------------------------- step
@@ -436,9 +443,8 @@ class LLMEngine:
         outputs: List[RequestOutput] = []
         progressed = False
         # ---- prompt pool
-        if self._prompt_inflight is not None and self._prompt_inflight[0].done():
-            pending, outs_p, ids, lane = self._prompt_inflight
-            self._prompt_inflight = None
+        while self._prompt_queue and self._prompt_queue[0][0].done():          # in launch order
+            pending, outs_p, ids, lane = self._prompt_queue.popleft()
             sampled = pending.resolve()
             live = [(g, o) for g, o in zip(outs_p.scheduled_seq_groups, sampled)
                     if g.get_seqs(status=SequenceStatus.RUNNING)]              # not aborted meanwhile
@@ -446,7 +452,7 @@ class LLMEngine:
                                                    groups=[g for g, _ in live], lane=lane)
             self.schedulers[lane].prompt_step_done(ids)
             progressed = True
-        if self._prompt_inflight is None:
+        if len(self._prompt_queue) < self._prompt_queue_depth:
             for turn in range(lanes):
                 lane = (self._next_prompt_lane + turn) % lanes
                 metas_p, outs_p = self.schedulers[lane].schedule_prompts()
@@ -466,7 +472,7 @@ class LLMEngine:
                               nw_epochs={s: self._slot_epoch[(lane, s)] for s in outs_p.blocks_to_nw})
                 pending = ex.launch_prompt(kwargs, lane) if lane else ex.launch_prompt(kwargs)
                 outs_p.scheduled_seq_groups = list(outs_p.scheduled_seq_groups)
-                self._prompt_inflight = (pending, outs_p, [m.request_id for m in metas_p], lane)
+                self._prompt_queue.append((pending, outs_p, [m.request_id for m in metas_p], lane))
                 progressed = True
         # ---- token pools: start every pool's next step, then collect every pool's previous one
         started: List[Optional[tuple]] = [None] * lanes
@@ -500,8 +506,8 @@ class LLMEngine:
                 self._launch_bookkeeping(started[lane][1], lane)
                 self._decode_inflight[lane] = started[lane]
             progressed = True
-        if not progressed and self._prompt_inflight is not None:
-            self._prompt_inflight[0].wait()                    # nothing else to do: wait for the prompt step
+        if not progressed and self._prompt_queue:
+            self._prompt_queue[0][0].wait()                    # nothing else to do: wait for the oldest prompt step
         self.scheduler.release_held()                          # aborted sequences whose last step has resolved
         return outputs
 

@@ -63,18 +63,21 @@ class _PoolPending:
         self.pending = pending
         self.executor = executor
         self.followers = followers
+        # a follower's acknowledgements arrive in the order of its commands: this step's is the one that brings
+        # its count of read ones up to the number sent so far (a later step may be queued behind this one)
+        self.need = {r: executor._acks_sent.get(r, 0) for r in followers}
 
     def done(self) -> bool:
         if not self.pending.done():
             return False
         for r in self.followers:
             self.executor._drain_acks(r)
-        return all(self.executor._unread_acks.get(r, 0) == 0 for r in self.followers)
+        return all(self.executor._acks_read.get(r, 0) >= self.need[r] for r in self.followers)
 
     def wait(self) -> None:
         self.pending.wait()
         for r in self.followers:
-            self.executor._await_acks(r)
+            self.executor._await_acks(r, self.need[r])
 
     def resolve(self):
         self.wait()
@@ -132,7 +135,8 @@ class PoolExecutor(ExecutorBase):
         self.token_pool = self.token_pools[0]
         self.supports_pipelined_split = self.split
         self.supports_deferred_samples = not self.split
-        self._unread_acks: Dict[int, int] = {}
+        self._acks_sent: Dict[int, int] = {}       # per follower: commands sent whose acknowledgement nobody waits for
+        self._acks_read: Dict[int, int] = {}       # ... and how many of those acknowledgements have been read
         try:
             self._call_all(self.all_ranks, "init_model")
             self._call_all(self.all_ranks, "load_model")
@@ -374,21 +378,23 @@ class PoolExecutor(ExecutorBase):
         """Reads the acknowledgements a rank has sent for commands whose result nobody waits for (a follower's
         deferred steps).  An error among them is raised here, one command late."""
         ch = self.channels[rank]
-        while self._unread_acks.get(rank, 0) > 0 and ch.poll(0.0):
-            status, result = self._recv(rank, time.monotonic() + _control_timeout())
-            self._unread_acks[rank] -= 1
-            if status == "error":
-                raise RuntimeError(f"worker {rank} failed: {result}")
+        while self._acks_read.get(rank, 0) < self._acks_sent.get(rank, 0) and ch.poll(0.0):
+            self._read_ack(rank)
+
+    def _read_ack(self, rank: int) -> None:
+        status, result = self._recv(rank, time.monotonic() + _control_timeout())
+        self._acks_read[rank] = self._acks_read.get(rank, 0) + 1
+        if status == "error":
+            raise RuntimeError(f"worker {rank} failed: {result}")
 
     def _owes_ack(self, rank: int) -> None:
-        self._unread_acks[rank] = self._unread_acks.get(rank, 0) + 1
+        self._acks_sent[rank] = self._acks_sent.get(rank, 0) + 1
 
-    def _await_acks(self, rank: int) -> None:
-        while self._unread_acks.get(rank, 0) > 0:
-            status, result = self._recv(rank, time.monotonic() + _control_timeout())
-            self._unread_acks[rank] -= 1
-            if status == "error":
-                raise RuntimeError(f"worker {rank} failed: {result}")
+    def _await_acks(self, rank: int, upto: Optional[int] = None) -> None:
+        """Blocks until ``upto`` acknowledgements of the rank have been read (all that are owed by default)."""
+        target = self._acks_sent.get(rank, 0) if upto is None else upto
+        while self._acks_read.get(rank, 0) < target:
+            self._read_ack(rank)
 
     def execute_deferred(self, kwargs: dict):
         """A co-located pool's step with the samples left on the device: -> the first rank's PendingSamples.
