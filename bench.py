@@ -113,6 +113,7 @@ class ClosedLoop:
         self.prompt_len = prompt_len
         self.rng = random.Random(seed)
         self.vocab = engine.model_config.get_vocab_size()
+        self._token_range = range(self.vocab)
         self.params = SamplingParams(temperature=0.0, max_tokens=decode_len, ignore_eos=True)
         self.next_id = 0
         self.live = 0
@@ -134,7 +135,7 @@ class ClosedLoop:
         from splitwise_amd import SamplingParams
         rid = str(self.next_id)
         self.next_id += 1
-        prompt = [self.rng.randrange(self.vocab) for _ in range(self.prompt_len)]
+        prompt = self.rng.choices(self._token_range, k=self.prompt_len)      # (one call: the loop's own host time counts)
         params = self.params
         if self.next_id <= self.concurrency:
             # (optional) other lengths for the first cohort; the staggered admission alone spreads the completions

@@ -268,3 +268,33 @@ def test_a_prompt_that_extends_an_earlier_output_shares_only_blocks_a_prompt_ste
     else:
         assert table_b[:4] == table_a[:4]
         assert computed == table_a[:len(computed)] and len(computed) >= 3
+
+
+def test_prompt_admission_waits_for_a_free_hand_off_slot():
+    """A hand-off slot can outlive its sequence's place in ``running`` (a pipelined split engine releases a finished
+    sequence only when the step that still reads its blocks has resolved).  With every slot taken the next prompt
+    waits; the reference's slot map raises "No more slots available" there (vllm/utils.py:141-143)."""
+    from splitwise_amd.utils import SeqToSlotMapper
+    cache = CacheConfig(BLOCK, 1.0, 1, "auto")
+    cache.num_gpu_blocks = cache.num_cpu_blocks = 64
+    sched = Scheduler(SchedulerConfig(64, 8, 64, 256), cache, None, track_prompt_blocks=True)
+    sched.seq_to_slot_mapper = SeqToSlotMapper(num_slots=2)
+    groups = []
+    for i in range(3):
+        seq = Sequence(i, None, [1, 2, 3, 4, 5], BLOCK)
+        groups.append(SequenceGroup(str(i), [seq], SamplingParams(max_tokens=4), time.monotonic()))
+        sched.add_seq_group(groups[-1])
+    metas, out = sched.schedule_prompts()
+    assert [m.request_id for m in metas] == ["0", "1"] and len(sched.waiting) == 1
+    metas, out = sched.schedule_prompts()
+    assert metas == [] and len(sched.waiting) == 1                  # no slot: later, not an exception
+    # sequence 0 finishes; the engine drops it from ``running`` at once but frees it one step later
+    seq0 = groups[0].get_seqs()[0]
+    from splitwise_amd.sequence import SequenceStatus
+    seq0.status = SequenceStatus.FINISHED_LENGTH_CAPPED
+    sched.free_finished_seq_groups()
+    assert sched.schedule_prompts()[0] == []                        # its slot is still taken
+    sched.free_seq(seq0)
+    metas, _ = sched.schedule_prompts()
+    assert [m.request_id for m in metas] == ["2"]
+    assert sched.seq_to_slot_mapper.get_slot_id(2) == 0             # the freed slot is the next one handed out

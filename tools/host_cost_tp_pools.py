@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "vllm-splitwise_amd"), os.path.join(ROOT, "tests"), os.path.join(ROOT, "tools")]
 
 
-def run(split: bool, pipeline: bool, tp: int, conc: int, steps: int, profile: bool):
+def run(split: bool, pipeline: bool, tp: int, conc: int, steps: int, profile: bool, token_pools: int = 1):
     import bench
     from host_step_workers import NullWorker
     from splitwise_amd import EngineArgs, LLMEngine
@@ -31,12 +31,17 @@ def run(split: bool, pipeline: bool, tp: int, conc: int, steps: int, profile: bo
         args = EngineArgs(model="llama-2-70b", dtype="bfloat16", sep_prompt_token=split, tensor_parallel_size=tp,
                           max_num_seqs=conc, max_model_len=2048, max_num_batched_tokens=4096, swap_space=0.001,
                           prefill_batch_tokens=2300, prefill_max_wait=0.08, pipeline_steps=pipeline,
-                          staged_prompt_cache=split and pipeline)
+                          staged_prompt_cache=split and pipeline, token_pools=token_pools)
         mc, cc, pc, sc, dc = args.create_engine_configs()
-        executor = PoolExecutor(mc, cc, pc, sc, dc, worker_cls=NullWorker, devices=[0] * pc.world_size)
+        if tp == 1:
+            from splitwise_amd.executor.splitwise_executor import SplitwiseExecutor
+            executor = SplitwiseExecutor(mc, cc, pc, sc, dc, worker_cls=NullWorker, prompt_device=0,
+                                         token_devices=[0] * token_pools)
+        else:
+            executor = PoolExecutor(mc, cc, pc, sc, dc, worker_cls=NullWorker, devices=[0] * pc.world_size)
         try:
             engine = LLMEngine(mc, cc, pc, sc, dc, executor=executor)
-            loop = bench.ClosedLoop(engine, conc, 772, 170, seed=0)
+            loop = bench.ClosedLoop(engine, conc * token_pools, 772, 170, seed=0)
             loop.fill()
             for _ in range(20):
                 loop.step(False)
@@ -57,9 +62,10 @@ def run(split: bool, pipeline: bool, tp: int, conc: int, steps: int, profile: bo
             if prof is not None:
                 prof.disable()
                 import pstats
-                pstats.Stats(prof).sort_stats("cumulative").print_stats(22)
-            return {"layout": (f"TP{tp}+TP{tp}" if split else f"TP{tp} co-located"), "ranks": pc.world_size,
-                    "pipelined": pipeline, "in_flight": conc, "ms_per_engine_call": round(dt / steps * 1e3, 3),
+                pstats.Stats(prof).sort_stats("tottime").print_stats(28)
+            layout = (f"TP{tp}+{token_pools}xTP{tp}" if split else f"TP{tp} co-located") if tp > 1 else f"1P+{token_pools}D"
+            return {"layout": layout, "ranks": pc.world_size,
+                    "pipelined": pipeline, "in_flight": conc * token_pools, "ms_per_engine_call": round(dt / steps * 1e3, 3),
                     "calls_with_a_prompt_step": kinds[True][0],
                     "ms_per_call_prompt": round(kinds[True][1] / max(kinds[True][0], 1) * 1e3, 3),
                     "ms_per_call_decode": round(kinds[False][1] / max(kinds[False][0], 1) * 1e3, 3)}
@@ -73,6 +79,7 @@ def main():
     ap.add_argument("--concurrency", type=int, default=256)
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--profile", action="store_true")
+    ap.add_argument("--token-pools", type=int, default=1, help="token pools fed by the prompt pool (with --tp 1: 1P+kD)")
     ap.add_argument("--only", default=None, help="split|colocated, lockstep|pipelined (comma separated)")
     args = ap.parse_args()
     print(f"# host cores here: {os.cpu_count()}", flush=True)
@@ -81,7 +88,10 @@ def main():
         for pipeline in (False, True):
             if only and not {"split" if split else "colocated", "pipelined" if pipeline else "lockstep"} >= only:
                 continue
-            print(json.dumps(run(split, pipeline, args.tp, args.concurrency, args.steps, args.profile)), flush=True)
+            if args.tp == 1 and not (split and pipeline):
+                continue                                   # pools of one GPU: the pipelined split engine only
+            print(json.dumps(run(split, pipeline, args.tp, args.concurrency, args.steps, args.profile,
+                                 args.token_pools if split else 1)), flush=True)
 
 
 if __name__ == "__main__":

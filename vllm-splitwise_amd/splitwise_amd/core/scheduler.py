@@ -206,6 +206,14 @@ class Scheduler:
                 break
             if padded - (total_len + prompt_len) > cfg.max_paddings:
                 break
+            # every admitted sequence takes a hand-off slot, and a slot can outlive its sequence's place in ``running``
+            # (a pipelined engine releases a finished sequence only when the step that still reads its blocks has
+            # resolved): no free slot means "later", where the reference raises (vllm/utils.py:141-143)
+            if self.seq_to_slot_mapper is not None:
+                need = sum(1 for seq in waiting_seqs
+                           if self.strict_reference or seq.seq_id not in self.seq_to_slot_mapper)
+                if need > self.seq_to_slot_mapper.num_free():
+                    break
             num_prompts += 1
             longest = max(longest, prompt_len)
             total_len += prompt_len

@@ -39,12 +39,18 @@ class RequestOutput:
     def from_seq_group(cls, seq_group: SequenceGroup) -> "RequestOutput":
         seqs = seq_group.get_seqs()
         n = seq_group.sampling_params.n
-        if len(seqs) > n:
-            seqs = sorted(seqs, key=lambda s: s.get_cumulative_logprob(), reverse=True)[:n]
         want_logprobs = seq_group.sampling_params.logprobs is not None
-        outputs = [CompletionOutput(seqs.index(s), s.output_text, list(s.get_output_token_ids()),
-                                    s.get_cumulative_logprob(), s.output_logprobs if want_logprobs else None,
-                                    SequenceStatus.get_finished_reason(s.status)) for s in seqs]
+        if len(seqs) == 1:                               # the common case, once per request and engine step
+            s = seqs[0]
+            outputs = [CompletionOutput(0, s.output_text, list(s.data.output_token_ids), s.data.cumulative_logprob,
+                                        s.output_logprobs if want_logprobs else None,
+                                        SequenceStatus.get_finished_reason(s.status))]
+        else:
+            if len(seqs) > n:
+                seqs = sorted(seqs, key=lambda s: s.get_cumulative_logprob(), reverse=True)[:n]
+            outputs = [CompletionOutput(seqs.index(s), s.output_text, list(s.get_output_token_ids()),
+                                        s.get_cumulative_logprob(), s.output_logprobs if want_logprobs else None,
+                                        SequenceStatus.get_finished_reason(s.status)) for s in seqs]
         finished = seq_group.is_finished()
         if finished:
             seq_group.set_finished_time(time.time())

@@ -210,28 +210,44 @@ class SequenceGroup:
     def set_finished_time(self, time: Optional[float]) -> None:
         self.metrics.finished_time = time
 
+    # (these run a few thousand times per engine step with hundreds of requests in flight, nearly all of them groups
+    # of one sequence: that case takes no list comprehension)
     def get_max_num_running_seqs(self) -> int:
         """vllm/sequence.py:363-378 without the beam-search branch."""
+        d = self.seqs_dict
+        if len(d) == 1 and self.sampling_params.best_of == 1:
+            for s in d.values():
+                return 0 if s.status in _FINISHED else 1
         if self.sampling_params.best_of > self.num_seqs():
             return self.sampling_params.best_of
         return self.num_unfinished_seqs()
 
     def get_seqs(self, status: Optional[SequenceStatus] = None) -> List[Sequence]:
+        d = self.seqs_dict
+        if len(d) == 1:
+            for s in d.values():
+                return [s] if status is None or s.status == status else []
         if status is None:
-            return list(self.seqs_dict.values())
-        return [s for s in self.seqs_dict.values() if s.status == status]
+            return list(d.values())
+        return [s for s in d.values() if s.status == status]
 
     def get_unfinished_seqs(self) -> List[Sequence]:
-        return [s for s in self.seqs_dict.values() if not s.is_finished()]
+        return [s for s in self.seqs_dict.values() if s.status not in _FINISHED]
 
     def get_finished_seqs(self) -> List[Sequence]:
-        return [s for s in self.seqs_dict.values() if s.is_finished()]
+        return [s for s in self.seqs_dict.values() if s.status in _FINISHED]
 
     def num_seqs(self, status: Optional[SequenceStatus] = None) -> int:
-        return len(self.get_seqs(status))
+        d = self.seqs_dict
+        if status is None:
+            return len(d)
+        if len(d) == 1:
+            for s in d.values():
+                return 1 if s.status == status else 0
+        return sum(1 for s in d.values() if s.status == status)
 
     def num_unfinished_seqs(self) -> int:
-        return len(self.get_unfinished_seqs())
+        return sum(1 for s in self.seqs_dict.values() if s.status not in _FINISHED)
 
     def num_finished_seqs(self) -> int:
         return len(self.get_finished_seqs())
@@ -252,7 +268,10 @@ class SequenceGroup:
         del self.seqs_dict[seq_id]
 
     def is_finished(self) -> bool:
-        return all(s.is_finished() for s in self.seqs_dict.values())
+        for s in self.seqs_dict.values():
+            if s.status not in _FINISHED:
+                return False
+        return True
 
     def __repr__(self) -> str:
         return f"SequenceGroup(request_id={self.request_id}, num_seqs={len(self.seqs_dict)})"

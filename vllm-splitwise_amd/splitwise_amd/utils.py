@@ -42,6 +42,9 @@ class SeqToSlotMapper:
     def free_seq(self, seq_id: int) -> None:
         self._free.appendleft(self._slot_of.pop(seq_id))
 
+    def num_free(self) -> int:
+        return len(self._free)
+
     def get_slot_id(self, seq_id: int) -> int:
         return self._slot_of[seq_id]
 
