@@ -719,40 +719,61 @@ prefill_attention_kernel(uint16_t* __restrict__ out, const uint16_t* __restrict_
 }
 
 // Joins the parts of the split form: out = sum_p O_p 2^(m_p - m) / sum_p l_p 2^(m_p - m), m = max_p m_p.
-// One workgroup per query row; a thread takes 4 head elements of one head at a time.
+// One thread per (query row, head, 4 head elements); all of a thread's loads are issued before the first is used
+// (the parts' maxima, sums and output pieces do not depend on each other), so the kernel runs at memory speed
+// rather than at one round trip per part.
+constexpr int kCtxReduceMaxParts = 8;                // parts joined per pass of the unrolled loads
+
 template <typename act_t>
 __global__ void __launch_bounds__(256)
 context_attention_reduce_kernel(uint16_t* __restrict__ out, const float* __restrict__ part_o,
                                 const float* __restrict__ part_m, const float* __restrict__ part_l,
                                 const int32_t* __restrict__ seq_starts, const int32_t* __restrict__ new_lens,
                                 int num_heads, int head_size, int num_parts, int64_t total_rows, int64_t out_stride) {
-  const int seq = blockIdx.y;
+  const int seq = blockIdx.z;
   if ((int)blockIdx.x >= new_lens[seq]) return;
   const int64_t row = (int64_t)seq_starts[seq] + blockIdx.x;
   const int per_head = head_size / 4;
-  for (int c = threadIdx.x; c < num_heads * per_head; c += 256) {
-    const int head = c / per_head, d = (c - head * per_head) * 4;
-    float m = -INFINITY;
-    for (int p = 0; p < num_parts; ++p) m = fmaxf(m, part_m[((int64_t)p * total_rows + row) * num_heads + head]);
-    float l = 0.f;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int p = 0; p < num_parts; ++p) {
+  const int c = blockIdx.y * 256 + threadIdx.x;
+  if (c >= num_heads * per_head) return;
+  const int head = c / per_head, d = (c - head * per_head) * 4;
+  float m = -INFINITY, l = 0.f;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int p0 = 0; p0 < num_parts; p0 += kCtxReduceMaxParts) {
+    float mp[kCtxReduceMaxParts], lp[kCtxReduceMaxParts];
+    float4 op[kCtxReduceMaxParts];
+#pragma unroll
+    for (int i = 0; i < kCtxReduceMaxParts; ++i) {
+      const int p = min(p0 + i, num_parts - 1);          // a repeated last part is given weight 0 below
       const int64_t idx = ((int64_t)p * total_rows + row) * num_heads + head;
-      const float mp = part_m[idx];
-      if (mp == -INFINITY) continue;                   // this part saw no key of the row
-      const float w = __builtin_amdgcn_exp2f(mp - m);
-      l = fmaf(part_l[idx], w, l);
-      const float4 o = *reinterpret_cast<const float4*>(part_o + idx * head_size + d);
-      acc.x = fmaf(o.x, w, acc.x);
-      acc.y = fmaf(o.y, w, acc.y);
-      acc.z = fmaf(o.z, w, acc.z);
-      acc.w = fmaf(o.w, w, acc.w);
+      mp[i] = part_m[idx];
+      lp[i] = part_l[idx];
+      op[i] = *reinterpret_cast<const float4*>(part_o + idx * head_size + d);
     }
-    const float inv = 1.f / l;
-    const uint32_t lo = (uint32_t)Conv<act_t>::from_float(acc.x * inv) | ((uint32_t)Conv<act_t>::from_float(acc.y * inv) << 16);
-    const uint32_t hi = (uint32_t)Conv<act_t>::from_float(acc.z * inv) | ((uint32_t)Conv<act_t>::from_float(acc.w * inv) << 16);
-    *reinterpret_cast<uint2*>(out + row * out_stride + (int64_t)head * head_size + d) = make_uint2(lo, hi);
+    float m_new = m;
+#pragma unroll
+    for (int i = 0; i < kCtxReduceMaxParts; ++i)
+      if (p0 + i < num_parts) m_new = fmaxf(m_new, mp[i]);
+    if (m_new == -INFINITY) continue;                    // none of these parts saw a key of the row
+    const float rescale = __builtin_amdgcn_exp2f(m - m_new);       // 0 while m is still -inf
+    l *= rescale;
+    acc.x *= rescale; acc.y *= rescale; acc.z *= rescale; acc.w *= rescale;
+    m = m_new;
+#pragma unroll
+    for (int i = 0; i < kCtxReduceMaxParts; ++i) {
+      const bool live = p0 + i < num_parts && mp[i] != -INFINITY;
+      const float w = live ? __builtin_amdgcn_exp2f(mp[i] - m) : 0.f;
+      l = fmaf(live ? lp[i] : 0.f, w, l);
+      acc.x = fmaf(live ? op[i].x : 0.f, w, acc.x);
+      acc.y = fmaf(live ? op[i].y : 0.f, w, acc.y);
+      acc.z = fmaf(live ? op[i].z : 0.f, w, acc.z);
+      acc.w = fmaf(live ? op[i].w : 0.f, w, acc.w);
+    }
   }
+  const float inv = 1.f / l;
+  const uint32_t lo = (uint32_t)Conv<act_t>::from_float(acc.x * inv) | ((uint32_t)Conv<act_t>::from_float(acc.y * inv) << 16);
+  const uint32_t hi = (uint32_t)Conv<act_t>::from_float(acc.z * inv) | ((uint32_t)Conv<act_t>::from_float(acc.w * inv) << 16);
+  *reinterpret_cast<uint2*>(out + row * out_stride + (int64_t)head * head_size + d) = make_uint2(lo, hi);
 }
 
 template <typename act_t, int HEAD, bool CTX, int WAVES, int KSW>
@@ -781,7 +802,8 @@ int launch_prefill_w(void* out, const void* q, const void* k, const void* v, con
       k_stride, v_stride, out_stride, sliding_window, num_seqs, max_seq_len, cx);
   SW_CHECK_LAUNCH();
   if (parts > 1) {
-    context_attention_reduce_kernel<act_t><<<dim3((unsigned)max_seq_len, (unsigned)num_seqs), 256, 0, stream>>>(
+    const unsigned col_groups = (unsigned)((num_heads * (HEAD / 4) + 255) / 256);
+    context_attention_reduce_kernel<act_t><<<dim3((unsigned)max_seq_len, col_groups, (unsigned)num_seqs), 256, 0, stream>>>(
         static_cast<uint16_t*>(out), cx.part_o, cx.part_m, cx.part_l, seq_starts, seq_lens, num_heads, HEAD, parts,
         cx.total_rows, out_stride);
     SW_CHECK_LAUNCH();
