@@ -333,18 +333,32 @@ prefill_attention_kernel(uint16_t* __restrict__ out, const uint16_t* __restrict_
     const int cfirst = c0 + t_lo * kPfStage;                                       // this workgroup's share of them
     const int cstages = min(t_hi, cstages_all) - t_lo;
     u32x4 ckreg[LOADS], cvreg[LOADS];
+    // The block numbers of a stage's pieces are read one stage before the pieces themselves (tfetch before cfetch): a
+    // piece's address depends on its block-table entry, and a wave that has to wait for that entry before it can even
+    // issue the loads stands still for a memory round trip in every stage.
+    int tkb[LOADS], tvb[LOADS];
+    auto tfetch = [&](int k0) {
+      static_for<LOADS>([&](auto IT) {
+        constexpr int it = decltype(IT)::value;
+        const int c = it * WAVES * 64 + tid;
+        if (CHUNKS % (WAVES * 64) == 0 || c < CHUNKS) {
+          tkb[it] = table[min(k0 + c / CPR, ctx - 1) / bs];
+          tvb[it] = table[(min(k0 + 8 * (c % (kPfStage / 8)), ctx - 1) & ~7) / bs];
+        }
+      });
+    };
     auto cfetch = [&](int k0) {
       static_for<LOADS>([&](auto IT) {
         constexpr int it = decltype(IT)::value;
         const int c = it * WAVES * 64 + tid;
         if (CHUNKS % (WAVES * 64) == 0 || c < CHUNKS) {
           const int kk = min(k0 + c / CPR, ctx - 1), ch = c % CPR;       // keys past the context: any valid address
-          const uint16_t* kp = cx.k_cache + (int64_t)table[kk / bs] * cx.k_block_stride +
+          const uint16_t* kp = cx.k_cache + (int64_t)tkb[it] * cx.k_block_stride +
                                (int64_t)kv_head * cx.k_head_stride + (int64_t)ch * bs * 8 + (kk % bs) * 8;
           ckreg[it] = *reinterpret_cast<const u32x4*>(kp);
           const int d = c / (kPfStage / 8), key0 = k0 + 8 * (c % (kPfStage / 8));
           const int kc = min(key0, ctx - 1) & ~7;
-          const uint16_t* vp = cx.v_cache + (int64_t)table[kc / bs] * cx.v_block_stride +
+          const uint16_t* vp = cx.v_cache + (int64_t)tvb[it] * cx.v_block_stride +
                                (int64_t)kv_head * cx.v_head_stride + (int64_t)d * bs + (kc % bs);
           u32x4 w = *reinterpret_cast<const u32x4*>(vp);
           const int valid = ctx - key0;                                  // never-written slots may hold NaN patterns
@@ -372,9 +386,12 @@ prefill_attention_kernel(uint16_t* __restrict__ out, const uint16_t* __restrict_
       });
     };
     if (cstages > 0) {
+      tfetch(cfirst);
       cfetch(cfirst);
+      if (cstages > 1) tfetch(cfirst + kPfStage);
       ccommit(0);
       if (cstages > 1) cfetch(cfirst + kPfStage);
+      if (cstages > 2) tfetch(cfirst + 2 * kPfStage);
       __syncthreads();
     }
     int cbuf = 0;
@@ -382,6 +399,7 @@ prefill_attention_kernel(uint16_t* __restrict__ out, const uint16_t* __restrict_
       const int k0 = cfirst + t * kPfStage;
       if (t + 1 < cstages) ccommit(cbuf ^ 1);
       if (t + 2 < cstages) cfetch(k0 + 2 * kPfStage);
+      if (t + 3 < cstages) tfetch(k0 + 3 * kPfStage);
       // (wave-uniform) this wave's window may begin after the stage
       const bool wanted = active && (sliding_window <= 0 || k0 + kPfStage > ctx + q0 - sliding_window + 1);
       if (wanted) {
