@@ -17,6 +17,8 @@ CASES = [("70B/TP4 16/2 bf16", 16, 2, torch.bfloat16, "auto"), ("64/8 bf16", 64,
          ("64/8 f16", 64, 8, torch.float16, "auto"), ("16/2 bf16 fp8", 16, 2, torch.bfloat16, "fp8_e5m2"),
          ("64/8 f16 fp8", 64, 8, torch.float16, "fp8_e5m2"), ("7B 32/32 bf16", 32, 32, torch.bfloat16, "auto")]
 for name, h, kvh, dt, kv in CASES:
+    if os.environ.get("GQA_CASES", "") not in name:
+        continue
     for s, ctx in ((64, 2048), (64, 4096), (128, 2048), (256, 2048), (256, 4096), (16, 8192), (8, 1024)):
         if s * ctx * kvh > 256 * 4096 * 8:
             continue

@@ -87,9 +87,12 @@ paged_attention_mfma_kernel(void* __restrict__ out_, float* __restrict__ exp_sum
   // fragments from the strip) is addressed to match:
   //   Q.K   step 2 m + h, slot (kq, j)  <->  head element 64 m + 16 kq + 8 h + j      (not 32 ks + 8 kq + j)
   //   P.V   step p,       slot (kq, j)  <->  token g_tok0 + 16 kq + 8 p + j           (not g_tok0 + 32 p + 8 kq + j)
-  constexpr bool WIDE = FP8 && HEAD % 64 == 0;
+  constexpr bool WIDE = FP8;
+  // the 8-wave form (small launches, two waves per SIMD at most) keeps the widening of an fp8 piece beside the
+  // products that use it; with 4 waves the compiler's own order is the faster one
+  constexpr bool PIN = FP8 && NW == 8;
   constexpr int DT = HEAD / 16;            // 16-dim tiles of O^T
-  static_assert(HEAD % 32 == 0 && (BS == 16 || BS == 32), "head size / block size of the matrix-core decode kernel");
+  static_assert(HEAD % 64 == 0 && (BS == 16 || BS == 32), "head size / block size of the matrix-core decode kernel");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   S* p_s = reinterpret_cast<S*>(smem);                                            // [NW][16][kPaMfmaPRow]
@@ -99,7 +102,7 @@ paged_attention_mfma_kernel(void* __restrict__ out_, float* __restrict__ exp_sum
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 15;                 // K: token of the tile; V: dim of the tile; everywhere else: head column
   const int kq = lane >> 4;                // quarter of the 32-wide k step this lane feeds
 
@@ -187,98 +190,66 @@ paged_attention_mfma_kernel(void* __restrict__ out_, float* __restrict__ exp_sum
   S* p_w = p_s + wave * kPaMfmaHeads * kPaMfmaPRow;
   const int n_groups = (tok_end - tok_begin + 63) >> 6;
 
-  for (int g = wave; g < n_groups; g += NW) {
+  // One 64-token group of a wave: its block-table entries, its K / V bytes as loaded, and the products.
+  //   16-bit cache: k[t][ks] / v[p * DT + dt] are the operand fragments themselves
+  //       key   (tile t, step ks): token g_tok0 + 16 t + r, dims 32 ks + 8 kq ..+7
+  //       value (step p, tile dt): dim 16 dt + r, tokens g_tok0 + 32 p + 8 kq ..+7
+  //   fp8 cache: k[t][m] is the 16-byte piece with this lane's slots of k steps 2 m and 2 m + 1, v[dt] the piece
+  //       with its slots of both P.V steps (tokens g_tok0 + 16 kq ..+15 of dim 16 dt + r); widened at use
+  constexpr int KR = WIDE ? KS / 2 : KS;
+  constexpr int VR = WIDE ? DT : 2 * DT;
+  constexpr int VT = WIDE ? 1 : 2;
+  struct Group {
+    int tk[4];                               // block of tokens g_tok0 + 16 t ..+15
+    pa_u32x4 k[4][KR], v[VR];
+  };
+  // a group starts on a multiple of 64 tokens, so each run of 16 tokens lies in one block and the four table
+  // entries are wave-uniform: scalar loads, and K base addresses in scalar registers (the wave index above is
+  // made uniform for the compiler's sake); runs past the context read the last block's entry
+  auto entries = [&](Group& f, int g) {
     const int g_tok0 = tok_begin + (g << 6);
-
-    // ------------------------------------------------ loads: 4 key tiles, 2 x DT value fragments
-    // key fragment (tile t, step ks): token g_tok0 + 16 t + r, dims 32 ks + 8 kq ..+7
-    pa_u32x4 kf[4][KS];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) f.tk[t] = block_table[min((g_tok0 + 16 * t) / BS, num_ctx_blocks - 1)];
+  };
+  auto fetch = [&](Group& f, int g) {
+    const int g_tok0 = tok_begin + (g << 6);
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      const int token = g_tok0 + 16 * t + r;
-      const int bidx = min(token / BS, num_ctx_blocks - 1);               // keep the table read in range
-      const char* kp = k_cache + (int64_t)block_table[bidx] * block_bytes + head_off;
-      const int off = token % BS;
-      if constexpr (WIDE) {                  // [HEAD/16][BS][16] bytes: a whole piece = this lane's slots of two k steps
+      const char* kp = k_cache + (int64_t)f.tk[t] * block_bytes + head_off;
+      const int off = (g_tok0 + 16 * t + r) % BS;
 #pragma unroll
-        for (int m = 0; m < KS / 2; ++m) {
-          const pa_u32x4 w = *reinterpret_cast<const pa_u32x4*>(kp + ((4 * m + kq) * BS + off) * 16);
-          kf[t][2 * m] = e5m2x8_to_f16x8(w[0], w[1]);
-          kf[t][2 * m + 1] = e5m2x8_to_f16x8(w[2], w[3]);
-        }
-      } else {
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-          if constexpr (FP8) {               // the lane's 8 dims are half a 16-byte piece
-            const uint2 w = *reinterpret_cast<const uint2*>(kp + ((2 * ks + (kq >> 1)) * BS + off) * 16 + 8 * (kq & 1));
-            kf[t][ks] = e5m2x8_to_f16x8(w.x, w.y);
-          } else {                           // [HEAD/8][BS][8] 16-bit elements
-            kf[t][ks] = *reinterpret_cast<const pa_u32x4*>(kp + ((4 * ks + kq) * BS + off) * 16);
-          }
-        }
-      }
+      for (int m = 0; m < KR; ++m)           // [HEAD/16][BS][16] bytes (fp8) or [HEAD/8][BS][8] 16-bit elements
+        f.k[t][m] = *reinterpret_cast<const pa_u32x4*>(kp + ((4 * m + kq) * BS + off) * 16);
     }
-    // value fragment (step p, dim tile dt): dim 16 dt + r, tokens g_tok0 + 32 p + 8 kq ..+7
-    // (WIDE: tokens g_tok0 + 16 kq + 8 p ..+7 -- one 16-byte load brings both steps' tokens)
-    pa_u32x4 vf[2][DT];
-    if constexpr (WIDE) {
-      const int token = g_tok0 + 16 * kq;
-      const int bidx = min(token / BS, num_ctx_blocks - 1);
-      const char* vp = v_cache + (int64_t)block_table[bidx] * block_bytes + head_off + (token % BS);
 #pragma unroll
-      for (int dt = 0; dt < DT; ++dt) {
-        const pa_u32x4 w = *reinterpret_cast<const pa_u32x4*>(vp + (16 * dt + r) * BS);
-        vf[0][dt] = e5m2x8_to_f16x8(w[0], w[1]);
-        vf[1][dt] = e5m2x8_to_f16x8(w[2], w[3]);
-      }
-      if (g_tok0 + 64 > ctx) {
-        // tokens past the context may hold anything, NaNs included, and 0 x NaN is NaN: clear them
+    for (int p = 0; p < VT; ++p) {
+      const int token = WIDE ? g_tok0 + 16 * kq : g_tok0 + 32 * p + 8 * kq;
+      const int run = WIDE ? kq : 2 * p + (kq >> 1);                     // (token - g_tok0) / 16
+      const int tv = run == 0 ? f.tk[0] : run == 1 ? f.tk[1] : run == 2 ? f.tk[2] : f.tk[3];
+      const char* vp = v_cache + (int64_t)tv * block_bytes + head_off + (token % BS) * CS;
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
-          const int live = ctx - (token + 8 * p);                             // elements 0 .. live-1 are real
-#pragma unroll
-          for (int w = 0; w < 4; ++w) {
-            const uint32_t mask = (2 * w < live ? 0x0000ffffu : 0u) | (2 * w + 1 < live ? 0xffff0000u : 0u);
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt) vf[p][dt][w] &= mask;
-          }
-        }
-      }
-    } else {
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      const int token = g_tok0 + 32 * p + 8 * kq;
-      const int bidx = min(token / BS, num_ctx_blocks - 1);
-      const char* vp = v_cache + (int64_t)block_table[bidx] * block_bytes + head_off + (token % BS) * CS;
-#pragma unroll
-      for (int dt = 0; dt < DT; ++dt) {
-        if constexpr (FP8) {
-          const uint2 w = *reinterpret_cast<const uint2*>(vp + (16 * dt + r) * BS);
-          vf[p][dt] = e5m2x8_to_f16x8(w.x, w.y);
-        } else {
-          vf[p][dt] = *reinterpret_cast<const pa_u32x4*>(vp + (16 * dt + r) * BS * 2);
-        }
-      }
-      if (g_tok0 + 32 * p + 32 > ctx) {
-        // tokens past the context may hold anything, NaNs included, and 0 x NaN is NaN: clear them
-        const int live = ctx - token;                                       // elements 0 .. live-1 are real
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-          const uint32_t mask = (2 * w < live ? 0x0000ffffu : 0u) | (2 * w + 1 < live ? 0xffff0000u : 0u);
-#pragma unroll
-          for (int dt = 0; dt < DT; ++dt) vf[p][dt][w] &= mask;
-        }
-      }
+      for (int dt = 0; dt < DT; ++dt)
+        f.v[p * DT + dt] = *reinterpret_cast<const pa_u32x4*>(vp + (16 * dt + r) * BS * CS);
     }
-    }
-
+  };
+  auto products = [&](const Group& f, int g) {
+    const int g_tok0 = tok_begin + (g << 6);
     // ---------------------------------------------------------------- Q.K
     pa_f32x4 s[4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      s[t] = pa_f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < 4; ++t) s[t] = pa_f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) s[t] = MM::run(kf[t][ks], qf[ks], s[t]);
+    for (int m = 0; m < KR; ++m) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        if constexpr (WIDE) {
+          s[t] = MM::run(e5m2x8_to_f16x8(f.k[t][m][0], f.k[t][m][1]), qf[2 * m], s[t]);
+          s[t] = MM::run(e5m2x8_to_f16x8(f.k[t][m][2], f.k[t][m][3]), qf[2 * m + 1], s[t]);
+          if (PIN && (t & 1)) __builtin_amdgcn_sched_barrier(0);
+        } else {
+          s[t] = MM::run(f.k[t][m], qf[m], s[t]);
+        }
+      }
     }
 
     // ------------------------------------------------------ online softmax
@@ -324,15 +295,66 @@ paged_attention_mfma_kernel(void* __restrict__ out_, float* __restrict__ exp_sum
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 
     // ---------------------------------------------------------------- P.V
+    // tokens past the context may hold anything, NaNs included, and 0 x NaN is NaN: their value elements are
+    // cleared (element e of a fragment is real when e < live)
+    auto live_mask = [](int live, int w) -> uint32_t {
+      return (2 * w < live ? 0x0000ffffu : 0u) | (2 * w + 1 < live ? 0xffff0000u : 0u);
+    };
+    if constexpr (WIDE) {
+      if (PIN) __builtin_amdgcn_sched_barrier(0);
+      const pa_u32x4 pf0 = *reinterpret_cast<const pa_u32x4*>(p_w + r * kPaMfmaPRow + 16 * kq);
+      const pa_u32x4 pf1 = *reinterpret_cast<const pa_u32x4*>(p_w + r * kPaMfmaPRow + 16 * kq + 8);
+      if (g_tok0 + 64 > ctx) {                                               // wave-uniform: the context's last group
+        const int live = ctx - (g_tok0 + 16 * kq);
+        pa_u32x4 m0, m1;
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      if (!WIDE && g_tok0 + 32 * p >= tok_end) break;                       // wave-uniform (WIDE: a step spans the group)
-      const pa_u32x4 pf =
-          *reinterpret_cast<const pa_u32x4*>(p_w + r * kPaMfmaPRow + (WIDE ? 16 * kq + 8 * p : 32 * p + 8 * kq));
+        for (int w = 0; w < 4; ++w) {
+          m0[w] = live_mask(live, w);
+          m1[w] = live_mask(live - 8, w);
+        }
 #pragma unroll
-      for (int dt = 0; dt < DT; ++dt) acc[dt] = MM::run(vf[p][dt], pf, acc[dt]);
+        for (int dt = 0; dt < DT; ++dt) {
+          acc[dt] = MM::run(e5m2x8_to_f16x8(f.v[dt][0], f.v[dt][1]) & m0, pf0, acc[dt]);
+          acc[dt] = MM::run(e5m2x8_to_f16x8(f.v[dt][2], f.v[dt][3]) & m1, pf1, acc[dt]);
+        }
+      } else {
+#pragma unroll
+        for (int d2 = 0; d2 < DT; d2 += 2) {
+#pragma unroll
+          for (int dt = d2; dt < d2 + 2; ++dt)
+            acc[dt] = MM::run(e5m2x8_to_f16x8(f.v[dt][0], f.v[dt][1]), pf0, acc[dt]);
+#pragma unroll
+          for (int dt = d2; dt < d2 + 2; ++dt)
+            acc[dt] = MM::run(e5m2x8_to_f16x8(f.v[dt][2], f.v[dt][3]), pf1, acc[dt]);
+          if (PIN) __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        if (g_tok0 + 32 * p >= tok_end) break;                               // wave-uniform
+        const pa_u32x4 pf = *reinterpret_cast<const pa_u32x4*>(p_w + r * kPaMfmaPRow + 32 * p + 8 * kq);
+        if (g_tok0 + 32 * p + 32 > ctx) {
+          const int live = ctx - (g_tok0 + 32 * p + 8 * kq);
+          pa_u32x4 mk;
+#pragma unroll
+          for (int w = 0; w < 4; ++w) mk[w] = live_mask(live, w);
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt) acc[dt] = MM::run(f.v[p * DT + dt] & mk, pf, acc[dt]);
+        } else {
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt) acc[dt] = MM::run(f.v[p * DT + dt], pf, acc[dt]);
+        }
+      }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");                  // the strip is rewritten next group
+  };
+
+  for (int g = wave; g < n_groups; g += NW) {
+    Group a;
+    entries(a, g);
+    fetch(a, g);
+    products(a, g);
   }
 
   // ------------------------------------------------ merge the four waves
