@@ -79,6 +79,7 @@ class FakeWorker:
         self.distributed_init_method = distributed_init_method
         self.distributed_store = distributed_store
         self.exchange = kv_transport_init["exchange"] if kv_transport_init else None
+        self.transport = kv_transport_init.get("transport", "kernel") if kv_transport_init else None
         self.dir = os.environ.get("SPLITWISE_DRYRUN_DIR") or os.environ["SPLIT_FAKE_DIR"]
         self.model_runner = _FakeRunner()
         self.kvcache_comm_manager = _FakeCommManager() if not self.mixed else None
@@ -149,6 +150,8 @@ class FakeWorker:
             return
         if os.environ.get("SPLIT_FAKE_DIE_IN_HANDSHAKE") == str(self.rank):
             os._exit(3)                                    # a worker that dies before it has handed anything in
+        if os.environ.get("SPLIT_FAKE_DIE_WITH_TRANSPORT") == self.transport and not self.is_prompt:
+            os._exit(3)                                    # a transport that does not come up on this node
         def swap(obj, index):
             return self.exchange(obj) if len(self.peers) == 1 else self.exchange(obj, index)
 

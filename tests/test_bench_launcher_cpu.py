@@ -93,3 +93,26 @@ def test_a_leg_that_cannot_start_is_reported_and_the_run_goes_on():
     assert proc.returncode == 0 and line["value"] > 0
     failed = line["legs"]["asymmetric"]
     assert "value" not in failed and "token worker 1" in failed["error"], failed
+
+
+def test_headline_falls_back_to_the_runtime_transport_and_then_to_the_colocated_leg():
+    # the token worker dies in the handshake of the kernel transport only: the pairs run again over the runtime
+    # transport and that leg is the headline, named as such
+    proc, lines = _run([sys.executable, "bench.py", "--gpus", "2"] + SMALL,
+                       extra_env={"SPLIT_FAKE_DIE_WITH_TRANSPORT": "kernel"})
+    assert len(lines) == 1, (lines, proc.stderr[-2000:])
+    line = json.loads(lines[0])
+    assert proc.returncode == 0 and line["value"] > 0
+    assert list(line["legs"]) == ["pairs", "pairs_runtime_transport", "colocated"]
+    assert "error" in line["legs"]["pairs"] and line["legs"]["pairs_runtime_transport"]["value"] == line["value"]
+    assert line["config"]["headline_leg"] == "pairs_runtime_transport" and line["config"]["kv_transport"] == "runtime"
+    assert "pairs) failed" in line["error"] and line["vs_colocated"] > 0
+    # it dies whatever the transport: the co-located leg of the same GPUs is what the line reports, and says so
+    proc, lines = _run([sys.executable, "bench.py", "--gpus", "2"] + SMALL,
+                       extra_env={"SPLIT_FAKE_DIE_IN_HANDSHAKE": "1"})
+    assert len(lines) == 1, (lines, proc.stderr[-2000:])
+    line = json.loads(lines[0])
+    assert proc.returncode == 0 and line["value"] == line["legs"]["colocated"]["value"] > 0
+    assert line["config"]["headline_leg"] == "colocated" and line["config"]["parallelism"] == "2x(co-located)"
+    assert "no KV migration" in line["config"]["workload"] and "failed" in line["error"]
+    assert line["kv_migration"] is None and line["vs_colocated"] is None

@@ -149,6 +149,7 @@ def run_leg(leg: Dict[str, Any], common: Dict[str, Any], store_port: int, workdi
         # RCCL refuses several ranks on one device: the rehearsal's tensor-parallel groups run over gloo (the
         # all-reduces of up to 8 MiB still go through the peer-read kernel)
         env.setdefault("SPLITWISE_TP_BACKEND", "gloo")
+    env.update(leg.get("env", {}))
     procs: List[subprocess.Popen] = []
     logs = []
     n = len(leg["replicas"])
@@ -294,7 +295,7 @@ def main(args) -> int:
     signal.signal(signal.SIGTERM, on_term)
     with tempfile.TemporaryDirectory(prefix="splitwise_bench_") as workdir:
         keep = os.environ.get("SPLITWISE_BENCH_LOG_DIR")
-        for leg in plan:
+        for leg in plan:                  # (the list may grow by a fallback leg while it is walked)
             left = args.budget_s - (time.monotonic() - began)
             if leg["role"] != "primary" and left < 60:
                 summaries[leg["name"]] = {"layout": leg["layout"], "skipped": "time budget of the run used up"}
@@ -306,6 +307,9 @@ def main(args) -> int:
             except LegFailed as exc:
                 summaries[leg["name"]] = {"layout": leg["layout"], "error": str(exc)[-1500:]}
                 print(f"[bench] {exc}", file=sys.stderr, flush=True)
+                fallback = runtime_transport_fallback(leg)
+                if fallback is not None:
+                    plan.insert(plan.index(leg) + 1, fallback)
             if keep:
                 import shutil
                 os.makedirs(keep, exist_ok=True)
@@ -315,9 +319,34 @@ def main(args) -> int:
     return emit()
 
 
+def runtime_transport_fallback(leg: Dict[str, Any]) -> Optional[Dict[str, Any]]:
+    """The headline leg once more with the KV blocks moved by the HIP runtime's device-to-device copies instead of
+    the push kernel's stores into the peer's mapped cache (worker/kv_comm.py, transport "runtime"), for a node on
+    which the kernel transport does not come up.  Only for the headline leg, only once, and not if the run already
+    asked for that transport."""
+    if leg["role"] != "primary" or not any(r["kind"] == "split" for r in leg["replicas"]):
+        return None
+    if os.environ.get("SPLITWISE_KV_TRANSPORT", "kernel") != "kernel":
+        return None
+    return {"name": leg["name"] + "_runtime_transport", "role": "primary_fallback", "of": leg["name"],
+            "replicas": leg["replicas"], "layout": leg["layout"], "env": {"SPLITWISE_KV_TRANSPORT": "runtime"}}
+
+
 def compose(args, n: int, plan, summaries: Dict[str, Any], one_gpu: bool, dtype: str) -> Dict[str, Any]:
-    primary = summaries.get("pairs") or summaries.get(plan[0]["name"]) or {}
+    # the headline: the first leg; if it failed, the same layout over the runtime transport; if that failed too,
+    # the co-located leg of the same GPUs, named as such in the line
     primary_leg = plan[0]
+    note = None
+    for leg in plan:
+        if leg is plan[0] or leg["role"] == "primary_fallback" or (leg["role"] == "colocated" and
+                                                                    leg.get("of") == plan[0]["name"]):
+            if "value" in summaries.get(leg["name"], {}):
+                if leg is not plan[0]:
+                    note = (f"the headline leg ({plan[0]['name']}) failed: value is the leg {leg['name']} "
+                            f"({leg['layout']}); see legs")
+                primary_leg = leg
+                break
+    primary = summaries.get(primary_leg["name"]) or {}
     ok = "value" in primary
     dtype_tag = {"bfloat16": "bf16", "float16": "f16", "half": "f16", "float32": "f32"}.get(dtype, dtype)
     for leg in plan:                      # every leg against its co-located counterpart
@@ -331,6 +360,11 @@ def compose(args, n: int, plan, summaries: Dict[str, Any], one_gpu: bool, dtype:
                     s["vs_colocated"] = round(s["per_gpu_tok_s"] / max(colo["per_gpu_tok_s"], 1e-9), 4)
                     s["colocated_leg"] = leg["name"]
     path = "device-local copies (one-GPU rehearsal: every worker shares device 0)" if one_gpu else "xGMI"
+    moved = f"KV blocks pushed prompt->token over {path}"
+    if primary_leg["role"] == "colocated":
+        moved = "no KV migration (co-located replicas: the split legs failed)"
+    elif primary_leg["role"] == "primary_fallback":
+        moved += " by the HIP runtime's copies (the push kernel's transport failed)"
     state_tag = "steady state" if primary.get("steady_state") else "RAMP (not steady state)"
     model_tag = "Llama-2-7B" if args.model == "llama-2-7b" else args.model
     line = {
@@ -339,13 +373,16 @@ def compose(args, n: int, plan, summaries: Dict[str, Any], one_gpu: bool, dtype:
         "warmup": args.warmup, "ms_per_step": primary.get("ms_per_step"), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": dtype_tag, "data": "synthetic",
         "config": {
-            "workload": f"{args.model} {dtype_tag}, {primary_leg['layout']}: KV blocks pushed prompt->token over {path}, "
+            "workload": f"{args.model} {dtype_tag}, {primary_leg['layout']}: {moved}, "
                         f"closed loop, {state_tag}: {primary.get('live_min')} requests in flight per replica at least "
                         f"({args.concurrency} per token GPU asked for), prefill {args.prompt_len} / decode "
                         f"{args.decode_len} tokens, random-init weights, SLO TTFT<={SLO_TTFT}s TPOT<={SLO_TPOT}s",
             "parallelism": primary_leg["layout"], "concurrency_target": args.concurrency,
             "live_min": primary.get("live_min"), "steady_state": primary.get("steady_state"),
             "pipeline_steps": primary.get("pipelined"), "one_gpu_rehearsal": one_gpu,
+            "headline_leg": primary_leg["name"],
+            "kv_transport": primary_leg.get("env", {}).get("SPLITWISE_KV_TRANSPORT",
+                                                            os.environ.get("SPLITWISE_KV_TRANSPORT", "kernel")),
             "prefill_batch_tokens": args.prefill_batch_tokens, "prefill_max_wait_s": args.prefill_max_wait},
         "throughput_tok_s": primary.get("throughput_tok_s"), "slo_attainment": primary.get("slo_attainment"),
         "vs_colocated": primary.get("vs_colocated"),
@@ -356,4 +393,6 @@ def compose(args, n: int, plan, summaries: Dict[str, Any], one_gpu: bool, dtype:
     }
     if not ok:
         line["error"] = f"the headline leg ({primary_leg['name']}) did not produce a result: see legs"
+    elif note:
+        line["error"] = note
     return line
