@@ -31,6 +31,7 @@ namespace sw {
 
 constexpr int kPaThreads = 256;
 constexpr int kPaWaves = 4;
+constexpr int kPaLeanUpTo = 4096;     // workgroups: launches up to this size take the vector kernel's LEAN form
 constexpr int kPartitionSize = 512;   // vllm/.../ops/paged_attn.py:12 _PARTITION_SIZE
 
 template <typename act_t, bool FP8>
@@ -121,7 +122,13 @@ __device__ __forceinline__ void cache_pairs(const uint32_t* w, uint32_t* out) {
 template <typename act_t, bool FP8> struct PackedPath { static constexpr bool value = Dot2<act_t>::kAvailable && !FP8; };
 template <> struct PackedPath<f16_t, true> { static constexpr bool value = true; };
 
-template <typename act_t, bool FP8, int HEAD, int BS, int QG>
+// LEAN: the group's block-table entries are read once (the P.V phase takes block b's entry from lane b * BS of
+// the Q.K phase's read instead of reading the table again in front of every block's loads) and the wave index
+// is handed to the compiler as uniform, which moves the P.V address arithmetic to the scalar unit.  Faster
+// wherever a wave's chain of dependent loads shows -- launches of a few thousand workgroups or fewer (8 x 1024
+// tokens 24.5 -> 22 us, 4 x 1024 20.8 -> 16.6, 128 x 860 311 -> 306) and every fp8 launch (256 x 860: 325 ->
+// 305 us) -- and 0.4-1.6 % slower on the largest 16-bit launches, which keep the plain form.
+template <typename act_t, bool FP8, int HEAD, int BS, int QG, bool LEAN>
 __global__ void __launch_bounds__(kPaThreads)
 paged_attention_kernel(void* __restrict__ out_,            // v1: [S,H,HEAD]; v2: tmp_out [S,H,P,HEAD]
                        float* __restrict__ exp_sums,       // v2 only [S,H,P]
@@ -157,7 +164,7 @@ paged_attention_kernel(void* __restrict__ out_,            // v1: [S,H,HEAD]; v2
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave = LEAN ? __builtin_amdgcn_readfirstlane(tid >> 6) : tid >> 6;
   // Workgroups go to the 8 XCDs round robin in launch order.  All head groups of a sequence walk
   // the same block table and the same cache blocks (a block holds its heads side by side), so
   // they are renumbered to run on ONE XCD, next to each other in time: its L2 and its address
@@ -236,15 +243,15 @@ paged_attention_kernel(void* __restrict__ out_,            // v1: [S,H,HEAD]; v2
     const int g_tok0 = tok_begin + (g << 6);
     const int token = g_tok0 + lane;
     const bool valid = token < tok_end;
+    // lane l holds the table entry of its token's block (blocks past the context repeat the last entry)
+    const int my_entry = block_table[min(g_tok0 / BS + blk_in_group, num_ctx_blocks - 1)];
 
     // ---------------------------------------------------------------- Q.K
     float qk[QG];
 #pragma unroll
     for (int h = 0; h < QG; ++h) qk[h] = 0.f;
     {
-      int bidx = g_tok0 / BS + blk_in_group;
-      bidx = min(bidx, num_ctx_blocks - 1);                 // keep the table read in range
-      const int64_t phys = block_table[bidx];
+      const int64_t phys = my_entry;
       const char* kp = k_cache + (phys * kv_block_stride + (int64_t)kv_head * kv_head_stride) * CS +
                        off_in_blk * 16;
 #pragma unroll
@@ -315,7 +322,7 @@ paged_attention_kernel(void* __restrict__ out_,            // v1: [S,H,HEAD]; v2
       const int btok0 = g_tok0 + b * BS;
       if (btok0 >= tok_end) break;                          // wave-uniform
       const int bidx = btok0 / BS;
-      const int64_t phys = block_table[bidx];
+      const int64_t phys = LEAN ? __builtin_amdgcn_readlane(my_entry, b * BS) : block_table[bidx];
       const char* vp = v_cache + (phys * kv_block_stride + (int64_t)kv_head * kv_head_stride) * CS;
       const bool last_block = (bidx == num_ctx_blocks - 1);
       uint32_t vraw[NIT][4];
@@ -530,7 +537,11 @@ int launch_pa(const PaArgs& a) {
   dim3 grid(a.num_kv_heads * (g / QG), a.num_seqs, parts);
   const size_t smem = (size_t)QG * HEAD * 4 + (size_t)kPaWaves * QG * 64 * T::ES +
                       (size_t)kPaWaves * QG * HEAD * 4 + 2 * kPaWaves * QG * 4;
-  paged_attention_kernel<act_t, FP8, HEAD, BS, QG><<<grid, kPaThreads, smem, a.stream>>>(
+  // fp8 caches always take the lean form (there is no other instantiation for them)
+  const bool lean = FP8 || (int64_t)grid.x * grid.y * grid.z <= kPaLeanUpTo;
+  auto kernel = lean ? paged_attention_kernel<act_t, FP8, HEAD, BS, QG, true>
+                     : paged_attention_kernel<act_t, FP8, HEAD, BS, QG, FP8>;
+  kernel<<<grid, kPaThreads, smem, a.stream>>>(
       a.partitioned ? a.tmp_out : a.out, a.exp_sums, a.max_logits, a.q, a.k, a.v, a.num_heads,
       a.num_kv_heads, a.scale, a.block_tables, a.context_lens, a.max_num_blocks_per_seq, a.alibi,
       a.q_stride, a.kv_block_stride, a.kv_head_stride, a.partitioned);
