@@ -178,6 +178,37 @@ def test_bf16_queries_beyond_the_f16_range_over_an_fp8_cache(version, heads):
     torch.testing.assert_close(out.cpu().float(), ref.float(), atol=1e-2, rtol=1e-5)
 
 
+@pytest.mark.parametrize("version", ["v1", "v2"])
+@pytest.mark.parametrize("dtype,heads,block_size", [(torch.bfloat16, (32, 32), 16), (torch.float16, (32, 32), 32),
+                                                    (torch.bfloat16, (32, 8), 16)])
+def test_both_forms_of_the_vector_kernel_give_the_same_bits(version, dtype, heads, block_size):
+    """The vector kernel has two forms, picked by the number of workgroups of the launch (up to 4096: the group's
+    table entries are read once and handed from lane to lane; above: read in front of every block's loads).  The
+    arithmetic is the same, so a sequence must come out bit-identical whichever launch it is part of: 300 sequences
+    in one launch (9600 workgroups per partition; 2400 of the matrix-core kernel in the grouped-query case)
+    against the same sequences 50 at a time (1600 per partition), and against the oracle."""
+    random.seed(5)
+    torch.manual_seed(5)
+    h, kvh = heads
+    num_seqs, head_size, nb = 300, 128, 1024
+    scale = float(head_size ** -0.5)
+    query = torch.empty(num_seqs, h, head_size, dtype=dtype).uniform_(-scale, scale)
+    lens = [1, 15, 16, 17, 63, 64, 65, 512, 513, 700] + [random.randint(1, 700) for _ in range(num_seqs - 10)]
+    max_blocks = (max(lens) + block_size - 1) // block_size
+    block_tables = torch.tensor([[random.randint(0, nb - 1) for _ in range(max_blocks)] for _ in range(num_seqs)],
+                                dtype=torch.int)
+    context_lens = torch.tensor(lens, dtype=torch.int)
+    kc, vc = make_kv_caches(nb, block_size, kvh, head_size, dtype)
+    q, kcd, vcd, bt, cl = query.cuda(), kc.cuda(), vc.cuda(), block_tables.cuda(), context_lens.cuda()
+    whole = run_kernel(version, q, kcd, vcd, kvh, scale, bt, cl, block_size, None, "auto")
+    for lo in range(0, num_seqs, 50):
+        part = run_kernel(version, q[lo:lo + 50].contiguous(), kcd, vcd, kvh, scale, bt[lo:lo + 50].contiguous(),
+                          cl[lo:lo + 50].contiguous(), block_size, None, "auto")
+        assert torch.equal(part, whole[lo:lo + 50]), lo
+    ref = oattn.paged_attention(query[:40], kc, vc, block_tables[:40], context_lens[:40], scale, None)
+    torch.testing.assert_close(whole[:40].cpu().float(), ref.float(), atol=1e-3, rtol=1e-5)
+
+
 def test_strided_query_and_nan_tail():
     """The query is a slice of a fused qkv tensor (q_stride != H*D), and the unused tail of
     the last block holds NaNs that must not leak (attention_kernels.cu:342-351)."""
