@@ -116,3 +116,9 @@ def test_headline_falls_back_to_the_runtime_transport_and_then_to_the_colocated_
     assert line["config"]["headline_leg"] == "colocated" and line["config"]["parallelism"] == "2x(co-located)"
     assert "no KV migration" in line["config"]["workload"] and "failed" in line["error"]
     assert line["kv_migration"] is None and line["vs_colocated"] is None
+    # ... even when the failed legs have used the run's time budget up: the line is owed a value
+    proc, lines = _run([sys.executable, "bench.py", "--gpus", "2", "--budget-s", "1"] + SMALL,
+                       extra_env={"SPLIT_FAKE_DIE_IN_HANDSHAKE": "1"})
+    line = json.loads(lines[0])
+    assert proc.returncode == 0 and line["value"] == line["legs"]["colocated"]["value"] > 0
+    assert "skipped" in line["legs"]["pairs_runtime_transport"] and line["config"]["headline_leg"] == "colocated"

@@ -297,10 +297,15 @@ def main(args) -> int:
         keep = os.environ.get("SPLITWISE_BENCH_LOG_DIR")
         for leg in plan:                  # (the list may grow by a fallback leg while it is walked)
             left = args.budget_s - (time.monotonic() - began)
-            if leg["role"] != "primary" and left < 60:
+            # a run whose split legs failed (or hung until their time limit) still owes the line a value: the
+            # co-located leg of the same GPUs then runs whatever is left of the budget
+            owed = (leg["role"] == "colocated" and leg.get("of") == plan[0]["name"]
+                    and not any("value" in s for s in summaries.values()))
+            if leg["role"] != "primary" and left < 60 and not owed:
                 summaries[leg["name"]] = {"layout": leg["layout"], "skipped": "time budget of the run used up"}
                 continue
-            timeout = args.leg_timeout if leg["role"] == "primary" else min(args.leg_timeout, max(left, 60))
+            timeout = args.leg_timeout if leg["role"] == "primary" else min(args.leg_timeout,
+                                                                            max(left, 300 if owed else 60))
             try:
                 results = run_leg(leg, common, store.port, workdir, timeout, bench_path, active)
                 summaries[leg["name"]] = summarize(leg, results)
