@@ -150,6 +150,41 @@ def test_transport_self_test_between_two_processes(transport, blocks, kv_dtype):
         ex.shutdown()
 
 
+def test_push_workgroup_cap_is_measured_at_set_up(monkeypatch):
+    """Over a link the workgroup cap of a push launch is picked by measurement when the transport is set up
+    (here forced for a peer on the same device): every candidate is timed, the smallest one within 8 % of the
+    best is kept, the bytes counter does not see the trial pushes, and the reference's self-test still finds
+    every block on the other side."""
+    from splitwise_amd.engine.arg_utils import EngineArgs
+    from splitwise_amd.executor.splitwise_executor import SplitwiseExecutor
+    monkeypatch.setenv("SPLITWISE_KV_PUSH_CALIBRATE", "1")
+    monkeypatch.delenv("SPLITWISE_KV_PUSH_WORKGROUPS", raising=False)
+    blocks = 64
+    args = EngineArgs(model="llama-tiny", sep_prompt_token=True, enforce_eager=True, num_gpu_blocks_override=blocks,
+                      max_num_seqs=4, max_model_len=256, swap_space=0.01)
+    mc, cc, pc, sc, dc = args.create_engine_configs()
+    ex = SplitwiseExecutor(mc, cc, pc, sc, dc, num_gpu_blocks_override=blocks, prompt_device=0, token_device=0,
+                           transport="kernel")
+    try:
+        comm = ex.driver_worker.kvcache_comm_manager.kvcache_comm
+        table = comm.push_calibration[0]
+        assert sorted(table) == [16, 32, 64, 128, 256] and all(v > 0 for v in table.values())
+        chosen = comm.push_workgroups[0]
+        assert chosen in table and table[chosen] >= max(table.values()) / 1.08
+        assert all(table[c] < max(table.values()) / 1.08 for c in table if c < chosen)
+        assert ex.kv_bytes_pushed() == 0
+        ex._remote_call("set_gpucache")
+        ex.driver_worker.set_gpucache()
+        ex._remote_async("send_recv_kvcache_all")
+        ex.driver_worker.send_recv_kvcache_all()
+        ex._remote_wait()
+        ex._remote_call("check_gpucache")
+        ex.driver_worker.check_gpucache()
+        assert ex.kv_bytes_pushed() == 2 * mc.hf_config["num_hidden_layers"] * blocks * 16 * 2 * 64 * 2
+    finally:
+        ex.shutdown()
+
+
 @pytest.mark.parametrize("overlap", [True, False, "pipelined"])
 def test_split_engine_generates_like_the_cpu_model(overlap):
     """1 prompt worker + 1 token worker (two processes): every decode step runs on KV that was

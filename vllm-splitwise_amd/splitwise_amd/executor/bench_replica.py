@@ -123,7 +123,9 @@ def _kv_push_bandwidth(executor, same_device: bool, iters: int = 6):
     gbs = per_iter * iters / secs / 1e9
     peak = HBM_PEAK_GBS / 2 if same_device else XGMI_LINK_PEAK_GBS       # a local copy reads and writes HBM
     return {"achieved": round(gbs, 1), "peak": peak, "unit": "GB/s", "path": "local HBM" if same_device else "xGMI",
-            "frac": round(gbs / peak, 4), "bytes_per_iter": per_iter, "iters": iters}
+            "frac": round(gbs / peak, 4), "bytes_per_iter": per_iter, "iters": iters,
+            "push_workgroups": comm.push_workgroups[0],               # 0: one per 64 KiB chunk, uncapped
+            "push_calibration_gbs": comm.push_calibration.get(0)}     # {cap: GB/s} when set-up measured it
 
 
 def _roofline_from_profile(prof: Dict[str, float], where: str):

@@ -148,6 +148,7 @@ class KVCacheCommunicator:
         # workers on one GPU: tests, rehearsals) wants one per 64 KiB chunk
         env = os.environ.get("SPLITWISE_KV_PUSH_WORKGROUPS")
         self.push_workgroups = [int(env) if env is not None else (32 if p.remote else 0) for p in peers]
+        self.push_calibration: Dict[int, Dict[int, float]] = {}      # peer -> {workgroups: GB/s}, if measured
         # runtime transport state
         self.local_bytes: Optional[torch.Tensor] = None
 
@@ -218,6 +219,41 @@ class KVCacheCommunicator:
             with torch.cuda.stream(stream):
                 for dst, src, n in zip(dst_offsets, src_offsets, sizes):
                     target.bytes[dst:dst + n].copy_(self.local_bytes[src:src + n], non_blocking=True)
+
+    def calibrate_push_workgroups(self, peer: int = 0, candidates: Sequence[int] = (16, 32, 64, 128, 256),
+                                  max_blocks: int = 256, repeats: int = 3) -> int:
+        """Picks the workgroup cap of a push launch towards ``peer`` by measurement: the first blocks of layer 0
+        (K and V) are pushed with every candidate cap, and the smallest cap within 8 % of the best time wins -- the
+        workgroups a push does not need stay with the prompt step's own kernels.  How many a link needs is a
+        property of the node (link width, store latency), so it is measured where the worker runs, at set-up, when
+        neither cache holds anything yet.  Returns the cap; ``push_calibration[peer]`` keeps the GB/s per cap."""
+        target = self.peers[peer]
+        k_off, v_off = self.layer_offsets[0]
+        local_blocks = (v_off - k_off) // self.block_size
+        n = min(max_blocks, local_blocks, target.num_blocks)
+        if n <= 0 or self.transport != "kernel":
+            return self.push_workgroups[peer]
+        pushed_before = self.bytes_pushed
+        nbytes = 2 * n * self.block_size
+        table: Dict[int, float] = {}
+        try:
+            for cap in candidates:
+                self.push_workgroups[peer] = cap
+                self.put_many(0, [(0, n)], peer)                  # untimed: first touch of the mapping
+                start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                start.record(self.push_stream)
+                for _ in range(repeats):
+                    self.put_many(0, [(0, n)], peer)
+                end.record(self.push_stream)
+                end.synchronize()
+                table[cap] = nbytes * repeats / (start.elapsed_time(end) * 1e-3) / 1e9
+        finally:
+            self.bytes_pushed = pushed_before
+        best = max(table.values())
+        chosen = min(cap for cap, gbs in table.items() if gbs >= best / 1.08)
+        self.push_workgroups[peer] = chosen
+        self.push_calibration[peer] = {cap: round(gbs, 1) for cap, gbs in table.items()}
+        return chosen
 
     def put(self, sem_id: int, layer_id: int, block_start: int, num_blocks: int) -> None:
         del sem_id                                    # ordering is by stream, not by channel
@@ -343,6 +379,17 @@ class KVCacheCommManager:
         if self.transport == "runtime":
             comm.local_bytes = slab
         self.kvcache_comm = comm
+        if self.is_prompt_side and self.transport == "kernel" and "SPLITWISE_KV_PUSH_WORKGROUPS" not in os.environ:
+            # over a link the cap is measured (a device-local peer takes one workgroup per chunk, uncapped);
+            # SPLITWISE_KV_PUSH_CALIBRATE=1 measures it for local peers too, =0 keeps the default of 32
+            mode = os.environ.get("SPLITWISE_KV_PUSH_CALIBRATE", "")
+            for index, view in enumerate(peers):
+                if mode != "0" and (view.remote or mode == "1"):
+                    try:
+                        comm.calibrate_push_workgroups(index)
+                    except RuntimeError as exc:                          # keep the default, say so
+                        print(f"[kv transport] push calibration towards peer {index} failed ({exc}); "
+                              f"keeping {comm.push_workgroups[index]} workgroups", flush=True)
         for index in range(len(self.peer_ranks)):
             self._swap({"rank": self.rank, "ready": True}, index)        # both sides mapped before any put
 
