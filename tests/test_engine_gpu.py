@@ -395,3 +395,53 @@ def test_parallel_sampling_forks_share_the_prompt_and_copy_on_write(pipeline, bl
         SamplingParams(n=2, temperature=0.0)
     del llm
     torch.cuda.empty_cache()
+
+
+def test_regressions_the_reference_guards_against():
+    """tests/test_regression.py:14-44 and tests/engine/test_computed_prefix_blocks.py:10-34 of the reference, on a
+    small local model: a prompt beyond the model length is reported (ignored, no tokens), not dropped;
+    ``max_tokens=None`` runs up to the model length; a second request whose prompt consists of full blocks that
+    the first request has already computed runs to completion; and a deleted engine gives its memory back."""
+    import gc
+
+    from splitwise_amd import LLM, SamplingParams
+    random.seed(3)
+    base = torch.cuda.memory_allocated()
+    llm = LLM("llama-tiny", enforce_eager=True, num_gpu_blocks_override=128, max_num_seqs=8, max_model_len=96,
+              swap_space=0.01, enable_prefix_caching=True)
+    vocab = llm.llm_engine.model_config.get_vocab_size()
+    short, long = [random.randrange(vocab) for _ in range(6)], [random.randrange(vocab) for _ in range(1000)]
+    outs = llm.generate(prompt_token_ids=[short, long],
+                        sampling_params=SamplingParams(temperature=0.01, top_p=0.1, max_tokens=16))
+    assert len(outs) == 2 and len(outs[0].outputs[0].token_ids) == 16
+    assert outs[1].finished and outs[1].outputs[0].token_ids == []
+
+    outs = llm.generate(prompt_token_ids=[short], sampling_params=SamplingParams(temperature=0.0, max_tokens=None,
+                                                                                 ignore_eos=True))
+    # the reference stops a sequence once its length EXCEEDS the model length (vllm/engine/llm_engine.py:770-771)
+    assert len(outs) == 1 and len(short) + len(outs[0].outputs[0].token_ids) == 96 + 1
+    assert outs[0].outputs[0].finish_reason == "length"
+
+    engine = llm.llm_engine
+    first = [random.randrange(vocab) for _ in range(32)]            # two full blocks
+    engine.add_request("a", None, SamplingParams(temperature=0.0, max_tokens=4), prompt_token_ids=first + short)
+    engine.step()
+    engine.add_request("b", None, SamplingParams(temperature=0.0, max_tokens=4), prompt_token_ids=list(first))
+    done = {}
+    for _ in range(20):
+        for out in engine.step():
+            if out.finished:
+                done[out.request_id] = out.outputs[0].token_ids
+        if not engine.has_unfinished_requests():
+            break
+    assert sorted(done) == ["a", "b"] and all(len(t) == 4 for t in done.values())
+    _check_greedy(llm, [first + short, first], [types.SimpleNamespace(outputs=[types.SimpleNamespace(token_ids=done[k])])
+                                                for k in ("a", "b")], tol=3e-2)
+
+    del llm, engine
+    gc.collect()
+    # torch keeps one BLAS workspace per handle for the life of the process (76 MiB on this stack): not the
+    # engine's, so it is released the way torch offers before the engine's own footprint is judged
+    torch._C._cuda_clearCublasWorkspaces()
+    torch.cuda.empty_cache()
+    assert torch.cuda.memory_allocated() - base < 50 * 1024 * 1024
