@@ -64,3 +64,34 @@ def run(rank: int, world: int, init_method: str, queue) -> None:
         queue.put((rank, bad))
     except BaseException:                         # noqa: BLE001 - reported to the parent
         queue.put((rank, traceback.format_exc()))
+
+
+def run_init(rank: int, world: int, init_method: str, queue, sabotaged_rank: int) -> None:
+    """The way a worker brings the path up (init_custom_ar, behind its known-answer self-check), with the
+    all-reduce of ``sabotaged_rank`` made to return wrong sums (-1: nobody's)."""
+    try:
+        import torch
+        import torch.distributed as dist
+        from splitwise_amd.model_executor import custom_all_reduce as car
+        from splitwise_amd.model_executor import parallel_state
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world, init_method=init_method)
+        parallel_state.initialize_model_parallel(world)
+        if rank == sabotaged_rank:
+            real = car.CustomAllreduce.all_reduce_unreg
+
+            def wrong(self, inp, out=None, algorithm=0):
+                return real(self, inp, out, algorithm) + 1
+
+            car.CustomAllreduce.all_reduce_unreg = wrong
+        car.init_custom_ar(rank, world, parallel_state.get_tensor_model_parallel_group())
+        x = (torch.arange(4096, device="cuda") % 5 + rank).to(torch.float16)
+        y = parallel_state.tensor_model_parallel_all_reduce(x.clone())
+        want = ((torch.arange(4096, device="cuda") % 5) * world + world * (world - 1) // 2).to(torch.float16)
+        sums_right = bool(torch.equal(y, want)) or rank == sabotaged_rank and car.is_initialized()
+        queue.put((rank, (car.is_initialized(), sums_right)))
+        dist.barrier()
+        parallel_state.destroy_model_parallel()
+        dist.destroy_process_group()
+    except BaseException:                         # noqa: BLE001 - reported to the parent
+        queue.put((rank, traceback.format_exc()))

@@ -35,6 +35,32 @@ def test_all_reduce_matches_reference_order_bit_for_bit(world):
         assert bad == [], f"rank {rank}: {bad}"
 
 
+@pytest.mark.parametrize("sabotaged_rank", [-1, 1])
+def test_the_path_is_only_used_after_a_known_answer_check(sabotaged_rank):
+    """init_custom_ar reduces a known tensor in both forms before the path is trusted.  With every rank honest
+    the path comes up; with one rank whose peer-read sums are wrong (as on a node whose links do not behave) NO
+    rank uses it, and the tensor-parallel all-reduce still gives the right sums through the library."""
+    import ar_worker
+    world = 2
+    ctx = mp.get_context("spawn")
+    queue = ctx.Queue()
+    with tempfile.TemporaryDirectory() as tmp:
+        init_method = "file://" + os.path.join(tmp, "rendezvous")
+        procs = [ctx.Process(target=ar_worker.run_init, args=(r, world, init_method, queue, sabotaged_rank),
+                             daemon=True) for r in range(world)]
+        for p in procs:
+            p.start()
+        try:
+            results = dict(queue.get(timeout=150) for _ in range(world))
+        finally:
+            for p in procs:
+                p.join(timeout=10)
+                if p.is_alive():
+                    p.kill()
+    for rank in range(world):
+        assert results[rank] == (sabotaged_rank < 0, True), (rank, results[rank])
+
+
 def _rccl_single_rank(init_method: str, queue) -> None:
     """As much of the default ("nccl" = RCCL) collective path as one GPU allows: backend start-up, the
     tensor-parallel group helpers, a message above the peer-read kernel's 8 MiB limit (the size class that

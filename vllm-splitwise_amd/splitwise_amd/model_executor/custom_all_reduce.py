@@ -152,7 +152,35 @@ def init_custom_ar(rank: int, world_size: int, group=None) -> None:
         return
     if world_size not in _SUPPORTED_WORLD_SIZES:
         return
-    _HANDLE = CustomAllreduce(rank, world_size, group)
+    handle = CustomAllreduce(rank, world_size, group)
+    if _self_check(handle, rank, world_size, group):
+        _HANDLE = handle
+    else:
+        handle.close()
+        print(f"[all-reduce] rank {rank}: the peer-read all-reduce did not reproduce a known sum on this node; "
+              "small all-reduces go through the collective library instead", flush=True)
+
+
+def _self_check(handle: "CustomAllreduce", rank: int, world_size: int, group) -> bool:
+    """One all-reduce with a known answer, in both forms, before the path is trusted: peer reads over the links of
+    this node have to work, not only map.  The ranks then agree on the verdict (a MIN over their flags), so the
+    path is used by all of them or by none."""
+    ok = True
+    try:
+        for numel, algorithm in ((4096, 1), (512 * 1024, 2)):
+            base = torch.arange(numel, device="cuda") % 7
+            out = handle.all_reduce_unreg((base + rank).to(torch.bfloat16), algorithm=algorithm)
+            want = (base * world_size + world_size * (world_size - 1) // 2).to(torch.bfloat16)     # exact in bf16
+            ok = ok and bool(torch.equal(out, want))
+        torch.cuda.synchronize()
+        handle.check_status()
+    except Exception as exc:                        # noqa: BLE001 - any failure means "do not use this path"
+        print(f"[all-reduce] rank {rank}: self-check raised {exc!r}", flush=True)
+        ok = False
+    host_group = dist.get_backend(group) == "gloo"
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cpu" if host_group else "cuda")
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    return bool(int(flag.item()))
 
 
 def get_handle() -> Optional[CustomAllreduce]:
