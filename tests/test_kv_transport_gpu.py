@@ -185,6 +185,23 @@ def test_push_workgroup_cap_is_measured_at_set_up(monkeypatch):
         ex.shutdown()
 
 
+def test_a_transport_that_does_not_deliver_fails_at_set_up(monkeypatch):
+    """Before the first hand-off a few blocks with known bytes travel the real path and the token worker compares
+    what its cache then holds.  Here the prompt side's push is made to do nothing: the flag still arrives, the
+    bytes do not, and the executor's construction fails instead of a later decode step running on blocks that
+    never came."""
+    from splitwise_amd import _C
+    from splitwise_amd.engine.arg_utils import EngineArgs
+    from splitwise_amd.executor.splitwise_executor import SplitwiseExecutor
+    monkeypatch.setattr(_C.kv_ops, "kv_push_mapped", lambda *a, **k: None)
+    args = EngineArgs(model="llama-tiny", sep_prompt_token=True, enforce_eager=True, num_gpu_blocks_override=32,
+                      max_num_seqs=4, max_model_len=256, swap_space=0.01)
+    mc, cc, pc, sc, dc = args.create_engine_configs()
+    with pytest.raises(RuntimeError, match="set-up check did not arrive intact"):
+        SplitwiseExecutor(mc, cc, pc, sc, dc, num_gpu_blocks_override=32, prompt_device=0, token_device=0,
+                          transport="kernel")
+
+
 @pytest.mark.parametrize("overlap", [True, False, "pipelined"])
 def test_split_engine_generates_like_the_cpu_model(overlap):
     """1 prompt worker + 1 token worker (two processes): every decode step runs on KV that was

@@ -31,6 +31,8 @@ _MAX_SPINS = 5_000_000            # bounded wait, about 10 s
 
 
 _IPC_OPEN_TIMEOUT_S = 60.0
+_SETUP_WORD = MAX_SLOT_IDS + 44   # a word of the flag area that no hand-off slot uses: the set-up check's flag
+_SETUP_CHECK_TIMEOUT_S = 90.0     # the token side waits this long for the prompt side's known blocks
 
 
 class TransportSetupTimeout(RuntimeError):
@@ -276,6 +278,34 @@ class KVCacheCommunicator:
                 target.bytes[off:off + 4].copy_(word, non_blocking=True)      # after the data copies, in stream order
             word.record_stream(self.push_stream)
 
+    def store_flag_word(self, peer: int, word: int, value: int) -> None:
+        """``value`` into word ``word`` of the peer's flag area, behind everything queued on the push stream (the
+        mechanism of signal_and_flush without its epoch bookkeeping)."""
+        target = self.peers[peer]
+        if self.transport == "kernel":
+            _C.kv_ops.kv_signal(target.base + target.flags_offset, word, value, self.push_stream.cuda_stream)
+        else:
+            src = torch.tensor([value], dtype=torch.int32, device=self.device).view(torch.uint8)
+            off = target.flags_offset + 4 * word
+            with torch.cuda.stream(self._after_compute()):
+                target.bytes[off:off + 4].copy_(src, non_blocking=True)
+            src.record_stream(self.push_stream)
+
+    def wait_flag_word(self, word: int, value: int, seconds: float) -> bool:
+        """Host-synchronising: True once word ``word`` of the local flag area has reached ``value``, False after
+        ``seconds`` (bounded waits of the usual length, one after the other)."""
+        import time
+        flags = self.local_base + self.flags_offset
+        deadline = time.monotonic() + seconds
+        while True:
+            _C.kv_ops.kv_wait(flags, word, value, self.max_spins, self.status_host.data_ptr(), self._stream())
+            torch.cuda.synchronize(self.device)
+            if int(self.status_host[0]) == 0:
+                return True
+            self.status_host[0] = 0
+            if time.monotonic() > deadline:
+                return False
+
     def wait(self, sem_id: int, epoch: Optional[int] = None) -> None:
         if epoch is None:
             epoch = self.wait_epoch[sem_id] + 1
@@ -390,8 +420,40 @@ class KVCacheCommManager:
                     except RuntimeError as exc:                          # keep the default, say so
                         print(f"[kv transport] push calibration towards peer {index} failed ({exc}); "
                               f"keeping {comm.push_workgroups[index]} workgroups", flush=True)
+        verified = self._known_answer_check(comm, slab, layer_offsets[0][0], block_bytes, int(k0.shape[0]), peers)
         for index in range(len(self.peer_ranks)):
-            self._swap({"rank": self.rank, "ready": True}, index)        # both sides mapped before any put
+            # both sides mapped before any put; the token side's answer says whether the check's blocks arrived
+            answer = self._swap({"rank": self.rank, "ready": True, "verified": verified}, index)
+            if self.is_prompt_side and isinstance(answer, dict) and answer.get("verified") is False:
+                raise RuntimeError(f"KV transport ({self.transport}): the blocks of the set-up check did not arrive "
+                                   f"intact in the cache of rank {answer.get('rank')}")
+
+    def _known_answer_check(self, comm: "KVCacheCommunicator", slab: torch.Tensor, k_offset: int, block_bytes: int,
+                            num_blocks: int, peers: List[PeerCache]) -> Optional[bool]:
+        """Before the first real hand-off, a few blocks with known bytes travel the real path -- push (or copy),
+        flag word, wait -- and the token side compares what its cache then holds: a transport that maps but does
+        not deliver (or delivers something else) fails at set-up, loudly, not as wrong tokens later.  The prompt
+        side returns None; the token side its verdict, which travels back with the "ready" message."""
+        n = min(4, num_blocks, min(p.num_blocks for p in peers))
+        nbytes = n * block_bytes
+        pattern = ((torch.arange(nbytes, device=slab.device, dtype=torch.int64) * 131 + 7) % 251).to(torch.uint8)
+        if self.is_prompt_side:
+            pushed = comm.bytes_pushed
+            slab[k_offset:k_offset + nbytes].copy_(pattern)
+            for index in range(len(peers)):
+                comm.put_many(0, [(0, 0, n)], index)
+                comm.store_flag_word(index, _SETUP_WORD, 1)
+            comm.synchronize()
+            slab[k_offset:k_offset + nbytes].zero_()
+            torch.cuda.synchronize(slab.device)
+            comm.bytes_pushed = pushed
+            return None
+        arrived = comm.wait_flag_word(_SETUP_WORD, 1, _SETUP_CHECK_TIMEOUT_S)
+        intact = arrived and bool(torch.equal(slab[k_offset:k_offset + nbytes], pattern))
+        if not intact:
+            print(f"[kv transport] rank {self.rank}: set-up check failed ({'bytes differ' if arrived else 'no flag'})",
+                  flush=True)
+        return intact
 
     def destroy_comm(self) -> None:
         if self.kvcache_comm is not None:
