@@ -85,6 +85,10 @@ def parse_args():
     ap.add_argument("--kv-cache-dtype", default="auto", choices=["auto", "fp8_e5m2"])
     ap.add_argument("--dtype", default=None, help="activation dtype (default bf16, fp16 with --quantization)")
     ap.add_argument("--enforce-eager", action="store_true")
+    ap.add_argument("--overlap-prompt-decode", action="store_true",
+                    help="N = 1: prompt steps and decode steps on two streams of the one GPU (OverlapExecutor)")
+    ap.add_argument("--no-overlap-leg", action="store_true",
+                    help="N = 1: do not time the same workload once more with --overlap-prompt-decode (a child process)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--window-trace", type=int, default=0,
@@ -367,127 +371,186 @@ def main():
         from splitwise_amd.executor import bench_launch
         sys.exit(bench_launch.main(args))
 
-    from splitwise_amd import EngineArgs, LLMEngine
-    torch.cuda.set_device(0)
-    conc = args.concurrency
-    warmup = args.warmup
-    seq_blocks = -(-(args.prompt_len + args.decode_len + 1) // 16)
-    dtype = args.dtype or ("float16" if args.quantization else "bfloat16")
-    dtype_tag = {"bfloat16": "bf16", "float16": "f16", "half": "f16", "float32": "f32"}.get(dtype, dtype)
-    variant = dtype_tag + (f" {args.quantization} int4" if args.quantization else "") + \
-        (" fp8 KV cache" if args.kv_cache_dtype != "auto" else "")
-    engine = LLMEngine.from_engine_args(EngineArgs(
-        model=args.model, dtype=dtype, quantization=args.quantization, kv_cache_dtype=args.kv_cache_dtype,
-        max_num_seqs=conc, max_model_len=2048, max_num_batched_tokens=args.max_num_batched_tokens,
-        num_gpu_blocks_override=int(conc * seq_blocks * 1.25) + 64, swap_space=0.25,
-        enforce_eager=args.enforce_eager, max_context_len_to_capture=1024,
-        prefill_batch_tokens=args.prefill_batch_tokens, prefill_max_wait=args.prefill_max_wait,
-        pipeline_steps=not args.no_pipeline_steps))
-    loop = ClosedLoop(engine, conc, args.prompt_len, args.decode_len, seed=0)
-    loop.first_cohort = args.first_cohort
+    def run_single() -> dict:
+        """The timed run itself; everything it builds (engine, cache, graphs) dies with its frame."""
+        from splitwise_amd import EngineArgs, LLMEngine
+        torch.cuda.set_device(0)
+        conc = args.concurrency
+        warmup = args.warmup
+        seq_blocks = -(-(args.prompt_len + args.decode_len + 1) // 16)
+        dtype = args.dtype or ("float16" if args.quantization else "bfloat16")
+        dtype_tag = {"bfloat16": "bf16", "float16": "f16", "half": "f16", "float32": "f32"}.get(dtype, dtype)
+        variant = dtype_tag + (f" {args.quantization} int4" if args.quantization else "") + \
+            (" fp8 KV cache" if args.kv_cache_dtype != "auto" else "")
+        engine = LLMEngine.from_engine_args(EngineArgs(
+            model=args.model, dtype=dtype, quantization=args.quantization, kv_cache_dtype=args.kv_cache_dtype,
+            max_num_seqs=conc, max_model_len=2048, max_num_batched_tokens=args.max_num_batched_tokens,
+            num_gpu_blocks_override=int(conc * seq_blocks * 1.25) + 64, swap_space=0.25,
+            enforce_eager=args.enforce_eager, max_context_len_to_capture=1024,
+            prefill_batch_tokens=args.prefill_batch_tokens, prefill_max_wait=args.prefill_max_wait,
+            pipeline_steps=not args.no_pipeline_steps, overlap_prompt_decode=args.overlap_prompt_decode))
+        loop = ClosedLoop(engine, conc, args.prompt_len, args.decode_len, seed=0)
+        loop.first_cohort = args.first_cohort
 
-    # decode batches of the timed region: their sizes (all of them) and, for the roofline
-    # measurement, the block tables and context lengths of up to 12 spread over the region
-    runner = engine.model_executor.driver_worker.model_runner
-    samples = []
-    batch_sizes = []
-    orig_prepare = runner._prepare_decode
-    state = {"on": False, "count": 0}
-    stride = max(1, args.steps // 24)
+        # decode batches of the timed region: their sizes (all of them) and, for the roofline
+        # measurement, the block tables and context lengths of up to 12 spread over the region
+        runner = engine.model_executor.driver_worker.model_runner
+        samples = []
+        batch_sizes = []
+        orig_prepare = runner._prepare_decode
+        state = {"on": False, "count": 0}
+        stride = max(1, args.steps // 24)
 
-    def sampling_prepare(metas):
-        out = orig_prepare(metas)
-        if state["on"]:
-            n = sum(len(m.seq_data) for m in metas)
-            batch_sizes.append(n)
-            if state["count"] % stride == 0 and len(samples) < 12:
-                import copy
-                md = out[2]
-                keep = copy.copy(md)
-                keep.context_lens = md.context_lens[:n].clone()
-                keep.block_tables = md.block_tables[:n].clone()
-                keep.max_context_len = md.max_context_len
-                samples.append(keep)
-            state["count"] += 1
-        return out
+        def sampling_prepare(metas):
+            out = orig_prepare(metas)
+            if state["on"]:
+                n = sum(len(m.seq_data) for m in metas)
+                batch_sizes.append(n)
+                if state["count"] % stride == 0 and len(samples) < 12:
+                    import copy
+                    md = out[2]
+                    keep = copy.copy(md)
+                    keep.context_lens = md.context_lens[:n].clone()
+                    keep.block_tables = md.block_tables[:n].clone()
+                    keep.max_context_len = md.max_context_len
+                    samples.append(keep)
+                state["count"] += 1
+            return out
 
-    runner._prepare_decode = sampling_prepare
+        runner._prepare_decode = sampling_prepare
 
-    steady = True
-    if not args.no_fill:
-        steady = loop.fill()
-    for _ in range(warmup):
-        loop.step(False)
-    torch.cuda.synchronize()
-    state["on"] = True
-    loop.open_window()
-    t0 = time.perf_counter()
-    tokens = 0
-    trace = []                                   # (seconds since t0, tokens so far) after every timed step
-    for _ in range(args.steps):
-        tokens += loop.step(True)
-        trace.append((time.perf_counter() - t0, tokens, bool(getattr(engine, "last_scheduled_prompt_run", False))))
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    tokens += loop.close_window()
-    if args.window_trace:
-        # generated tok/s of every run of `window_trace` consecutive steps: how much a short window's figure
-        # depends on where in the request cycle it falls
-        w = args.window_trace
-        rates = []
-        for i in range(w, len(trace) + 1, w):
-            t_a, n_a = trace[i - w - 1][:2] if i > w else (0.0, 0)
-            t_b, n_b = trace[i - 1][:2]
-            rates.append((n_b - n_a) / (t_b - t_a))
-        print(f"tok/s per {w}-step window: " + " ".join(f"{r:.0f}" for r in rates) +
-              f" | min {min(rates):.0f} mean {sum(rates) / len(rates):.0f} max {max(rates):.0f}", file=sys.stderr, flush=True)
-        if len(trace) <= 60:                     # every step: kind scheduled in the call, tokens returned, host time
-            prev_t, prev_n = 0.0, 0
-            parts = []
-            for t, n, prompt in trace:
-                parts.append(f"{'P' if prompt else 'D'}{n - prev_n}:{(t - prev_t) * 1e3:.0f}ms")
-                prev_t, prev_n = t, n
-            print("steps: " + " ".join(parts), file=sys.stderr, flush=True)
-    state["on"] = False
+        steady = True
+        if not args.no_fill:
+            steady = loop.fill()
+        for _ in range(warmup):
+            loop.step(False)
+        torch.cuda.synchronize()
+        state["on"] = True
+        loop.open_window()
+        t0 = time.perf_counter()
+        tokens = 0
+        trace = []                                   # (seconds since t0, tokens so far) after every timed step
+        for _ in range(args.steps):
+            tokens += loop.step(True)
+            trace.append((time.perf_counter() - t0, tokens, bool(getattr(engine, "last_scheduled_prompt_run", False))))
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        tokens += loop.close_window()
+        if args.window_trace:
+            # generated tok/s of every run of `window_trace` consecutive steps: how much a short window's figure
+            # depends on where in the request cycle it falls
+            w = args.window_trace
+            rates = []
+            for i in range(w, len(trace) + 1, w):
+                t_a, n_a = trace[i - w - 1][:2] if i > w else (0.0, 0)
+                t_b, n_b = trace[i - 1][:2]
+                rates.append((n_b - n_a) / (t_b - t_a))
+            print(f"tok/s per {w}-step window: " + " ".join(f"{r:.0f}" for r in rates) +
+                  f" | min {min(rates):.0f} mean {sum(rates) / len(rates):.0f} max {max(rates):.0f}", file=sys.stderr, flush=True)
+            if len(trace) <= 60:                     # every step: kind scheduled in the call, tokens returned, host time
+                prev_t, prev_n = 0.0, 0
+                parts = []
+                for t, n, prompt in trace:
+                    parts.append(f"{'P' if prompt else 'D'}{n - prev_n}:{(t - prev_t) * 1e3:.0f}ms")
+                    prev_t, prev_n = t, n
+                print("steps: " + " ".join(parts), file=sys.stderr, flush=True)
+        state["on"] = False
 
-    good, total, met, seen, ttfts, tpots = loop.goodput_tokens()
-    win = loop.window_stats()
-    in_flight = win["live_min"] if win["live_min"] >= 0.95 * conc else win["live_mean"]
-    state_tag = "steady state" if (steady and not args.no_fill and win["live_min"] >= 0.95 * conc) else \
-        "RAMP (not steady state)"
-    result = {
-        "metric": "goodput (tok/s under TTFT+TBT SLO), " + ("Llama-2-7B" if args.model == "llama-2-7b" else args.model) + " co-located", "value": round(good / elapsed, 2),
-        "unit": "tok/s", "n_gpus": 1, "steps": args.steps, "warmup": warmup,
-        "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": dtype_tag, "data": "synthetic",
-        "config": {"workload": f"{args.model} {variant} co-located on 1 GPU, closed loop, {state_tag}: {in_flight:g} requests "
-                               f"in flight over the timed steps ({conc} asked for), "
-                               f"prefill {args.prompt_len} / decode {args.decode_len} tokens, random-init weights, "
-                               f"SLO TTFT<={SLO_TTFT}s TPOT<={SLO_TPOT}s",
-                   "concurrency": in_flight, "concurrency_target": conc,
-                   "live_min": win["live_min"], "live_mean": win["live_mean"],
-                   "decode_batch_min": min(batch_sizes) if batch_sizes else 0,
-                   "decode_batch_mean": round(sum(batch_sizes) / max(len(batch_sizes), 1), 1),
-                   "fill_steps": loop.fill_steps, "steady_state": state_tag == "steady state",
-                   "prompt_len": args.prompt_len, "decode_len": args.decode_len,
-                   "prefill_batch_tokens": args.prefill_batch_tokens, "prefill_max_wait_s": args.prefill_max_wait,
-                   "hip_graphs": not args.enforce_eager, "pipeline_steps": not args.no_pipeline_steps},
-        "throughput_tok_s": round(total / elapsed, 2),
-        "slo_attainment": round(met / max(seen, 1), 4),
-        "prompt_steps": loop.step_kinds[True][0],
-        "avg_prompt_step_ms": round(loop.step_kinds[True][1] / max(loop.step_kinds[True][0], 1) * 1e3, 2),
-        "decode_steps": loop.step_kinds[False][0],
-        "avg_decode_step_ms": round(loop.step_kinds[False][1] / max(loop.step_kinds[False][0], 1) * 1e3, 2),
-        "ttft_p50_ms": round(sorted(ttfts)[len(ttfts) // 2] * 1e3, 2) if ttfts else None,
-        "ttft_p99_ms": round(sorted(ttfts)[int(len(ttfts) * 0.99)] * 1e3, 2) if ttfts else None,
-        "tpot_p50_ms": round(sorted(tpots)[len(tpots) // 2] * 1e3, 2) if tpots else None,
-        "tpot_p99_ms": round(sorted(tpots)[int(len(tpots) * 0.99)] * 1e3, 2) if tpots else None,
-    }
-    if not args.no_roofline:
-        result["roofline"] = measure_attention_roofline(engine, samples)
+        good, total, met, seen, ttfts, tpots = loop.goodput_tokens()
+        win = loop.window_stats()
+        in_flight = win["live_min"] if win["live_min"] >= 0.95 * conc else win["live_mean"]
+        state_tag = "steady state" if (steady and not args.no_fill and win["live_min"] >= 0.95 * conc) else \
+            "RAMP (not steady state)"
+        result = {
+            "metric": "goodput (tok/s under TTFT+TBT SLO), " + ("Llama-2-7B" if args.model == "llama-2-7b" else args.model) + " co-located", "value": round(good / elapsed, 2),
+            "unit": "tok/s", "n_gpus": 1, "steps": args.steps, "warmup": warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": dtype_tag, "data": "synthetic",
+            "config": {"workload": f"{args.model} {variant} co-located on 1 GPU, closed loop, {state_tag}: {in_flight:g} requests "
+                                   f"in flight over the timed steps ({conc} asked for), "
+                                   f"prefill {args.prompt_len} / decode {args.decode_len} tokens, random-init weights, "
+                                   f"SLO TTFT<={SLO_TTFT}s TPOT<={SLO_TPOT}s"
+                                   + ("; prompt steps run BESIDE the decode steps on a second stream (every timed step "
+                                      "is a decode step; a call counts as a prompt step when prompts were waiting)"
+                                      if args.overlap_prompt_decode else ""),
+                       "concurrency": in_flight, "concurrency_target": conc,
+                       "live_min": win["live_min"], "live_mean": win["live_mean"],
+                       "decode_batch_min": min(batch_sizes) if batch_sizes else 0,
+                       "decode_batch_mean": round(sum(batch_sizes) / max(len(batch_sizes), 1), 1),
+                       "fill_steps": loop.fill_steps, "steady_state": state_tag == "steady state",
+                       "prompt_len": args.prompt_len, "decode_len": args.decode_len,
+                       "prefill_batch_tokens": args.prefill_batch_tokens, "prefill_max_wait_s": args.prefill_max_wait,
+                       "hip_graphs": not args.enforce_eager, "pipeline_steps": not args.no_pipeline_steps,
+                       "overlap_prompt_decode": args.overlap_prompt_decode},
+            "throughput_tok_s": round(total / elapsed, 2),
+            "slo_attainment": round(met / max(seen, 1), 4),
+            "prompt_steps": loop.step_kinds[True][0],
+            "avg_prompt_step_ms": round(loop.step_kinds[True][1] / max(loop.step_kinds[True][0], 1) * 1e3, 2),
+            "decode_steps": loop.step_kinds[False][0],
+            "avg_decode_step_ms": round(loop.step_kinds[False][1] / max(loop.step_kinds[False][0], 1) * 1e3, 2),
+            "ttft_p50_ms": round(sorted(ttfts)[len(ttfts) // 2] * 1e3, 2) if ttfts else None,
+            "ttft_p99_ms": round(sorted(ttfts)[int(len(ttfts) * 0.99)] * 1e3, 2) if ttfts else None,
+            "tpot_p50_ms": round(sorted(tpots)[len(tpots) // 2] * 1e3, 2) if tpots else None,
+            "tpot_p99_ms": round(sorted(tpots)[int(len(tpots) * 0.99)] * 1e3, 2) if tpots else None,
+        }
+        if not args.no_roofline:
+            result["roofline"] = measure_attention_roofline(engine, samples)
+            if args.overlap_prompt_decode and result["roofline"]:
+                result["roofline"]["note"] = ("launch durations of the kernel running alone; inside this run's steps it "
+                                              "shares the GPU with a prompt step's kernels")
+        return result
+
+    result = run_single()
+    import gc
+    gc.unfreeze()                   # (the engine parks its long-lived objects out of the collector's reach)
+    gc.collect()
+    torch.cuda.empty_cache()        # the cache and the weights go back: the overlap leg's child needs the room
+    print(f"after the timed run: {torch.cuda.mem_get_info()[0] / 2**30:.1f} GiB of device memory free, "
+          f"{torch.cuda.memory_allocated() / 2**30:.2f} GiB still allocated by this process, "
+          f"{torch.cuda.memory_reserved() / 2**30:.2f} GiB reserved", file=sys.stderr, flush=True)
+    if not (args.overlap_prompt_decode or args.no_overlap_leg or args.no_fill):
+        result["overlap_prompt_decode"] = overlap_leg(args, result["value"])
     if not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args.model, args.prompt_len, args.decode_len)
     print(json.dumps(result))
+
+
+def overlap_leg(args, default_value: float) -> dict:
+    """The same workload once more with the engine's ``overlap_prompt_decode`` option, in a child process of its
+    own (this process keeps its engine; the option's figure is reported beside the headline, never as it: the
+    headline's roofline is about kernels that have the GPU to themselves).  Whatever happens to the child, the
+    line of this process is printed."""
+    import subprocess
+    preload = os.environ.get("LD_PRELOAD", "")
+    if "rocprof" in preload or "ROCP_TOOL_LIBRARIES" in os.environ:
+        return {"skipped": "under a profiler: a second engine's kernels would land in the same trace"}
+    cmd = [sys.executable, os.path.abspath(__file__), "--overlap-prompt-decode", "--no-cpu-baseline", "--no-roofline",
+           "--steps", str(args.steps), "--warmup", str(args.warmup), "--concurrency", str(args.concurrency),
+           "--model", args.model, "--prompt-len", str(args.prompt_len), "--decode-len", str(args.decode_len),
+           "--max-num-batched-tokens", str(args.max_num_batched_tokens),
+           "--prefill-batch-tokens", str(args.prefill_batch_tokens), "--prefill-max-wait", str(args.prefill_max_wait),
+           "--kv-cache-dtype", args.kv_cache_dtype, "--first-cohort", args.first_cohort]
+    if args.quantization:
+        cmd += ["--quantization", args.quantization]
+    if args.dtype:
+        cmd += ["--dtype", args.dtype]
+    if args.enforce_eager:
+        cmd += ["--enforce-eager"]
+    try:
+        proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=420)
+        lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+        if proc.returncode != 0 or not lines:
+            return {"error": f"exit status {proc.returncode}: {proc.stderr[-400:]}"}
+        line = json.loads(lines[-1])
+        keep = ("value", "ms_per_step", "slo_attainment", "ttft_p50_ms", "ttft_p99_ms", "tpot_p50_ms", "tpot_p99_ms")
+        out = {k: line.get(k) for k in keep}
+        out["steady_state"] = line["config"].get("steady_state")
+        out["vs_default"] = round(line["value"] / max(default_value, 1e-9), 4)
+        out["what"] = ("prompt steps beside the decode steps on a second stream of the same GPU "
+                       "(EngineArgs.overlap_prompt_decode), same workload and SLO, timed in a child process")
+        return out
+    except (subprocess.TimeoutExpired, OSError, ValueError, KeyError) as exc:
+        return {"error": repr(exc)[:400]}
 
 
 if __name__ == "__main__":

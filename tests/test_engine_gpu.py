@@ -445,3 +445,51 @@ def test_regressions_the_reference_guards_against():
     torch._C._cuda_clearCublasWorkspaces()
     torch.cuda.empty_cache()
     assert torch.cuda.memory_allocated() - base < 50 * 1024 * 1024
+
+
+@pytest.mark.parametrize("enforce_eager,blocks", [(False, 512), (True, 512), (False, 40)])
+def test_prompt_steps_beside_decode_steps_on_one_gpu_match_the_cpu_model(enforce_eager, blocks):
+    """``overlap_prompt_decode``: the engine's split loop over ONE worker -- prompt steps on a stream of their own
+    beside the (pipelined, graph-replayed) decode steps, one cache, nothing to hand over.  Requests arrive while
+    others decode, one is aborted, and with 40 blocks sequences are preempted and recomputed; every finished
+    request's greedy tokens are judged by the CPU model, and they are the tokens of the plain co-located engine."""
+    from splitwise_amd import EngineArgs, LLMEngine, SamplingParams
+    from splitwise_amd.executor.overlap_executor import OverlapExecutor
+
+    def run(overlap):
+        random.seed(4)
+        engine = LLMEngine.from_engine_args(EngineArgs(
+            model="llama-tiny", max_num_seqs=12, max_model_len=256, swap_space=0.01, num_gpu_blocks_override=blocks,
+            pipeline_steps=True, enforce_eager=enforce_eager, overlap_prompt_decode=overlap))
+        assert isinstance(engine.model_executor, OverlapExecutor) == overlap and engine.pipeline_split == overlap
+        vocab = engine.model_config.get_vocab_size()
+        prompts = [[random.randrange(vocab) for _ in range(random.choice([1, 3, 17, 40, 64, 100]))] for _ in range(30)]
+        done, step, waiting = {}, 0, list(enumerate(prompts))
+        while waiting or engine.has_unfinished_requests():
+            if waiting and step % 2 == 0:
+                i, p = waiting.pop(0)
+                engine.add_request(str(i), None, SamplingParams(temperature=0.0, max_tokens=20 + i % 7, ignore_eos=True),
+                                   prompt_token_ids=p)
+            if step == 25:
+                engine.abort_request("5")
+            for out in engine.step():
+                if out.finished:
+                    done[out.request_id] = list(out.outputs[0].token_ids)
+            step += 1
+            assert step < 5000
+        free = engine.scheduler.block_manager.get_num_free_gpu_blocks()
+        preempted = getattr(engine.scheduler, "num_preemptions", 0)
+        return engine, prompts, done, free, preempted
+
+    engine, prompts, done, free, preempted = run(True)
+    assert free == blocks and sorted(done) == sorted(str(i) for i in range(30) if i != 5 or "5" in done)
+    assert (preempted > 0) == (blocks == 40)
+    llm = types.SimpleNamespace(llm_engine=engine)
+    ids = sorted(done, key=int)
+    _check_greedy(llm, [prompts[int(i)] for i in ids],
+                  [types.SimpleNamespace(outputs=[types.SimpleNamespace(token_ids=done[i])]) for i in ids], tol=3e-2)
+    del llm, engine
+    torch.cuda.empty_cache()
+    if blocks == 512:
+        _, _, plain, _, _ = run(False)
+        assert all(done[i] == plain[i] for i in done if i in plain and i != "5")

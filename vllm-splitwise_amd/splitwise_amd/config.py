@@ -178,6 +178,7 @@ class ParallelConfig:
         self.num_prompt_workers = 0
         self.num_token_workers = 0
         self.num_token_pools = token_pools if sep_prompt_token else 0
+        self.one_gpu_overlap = False      # both "pools" are one worker with two streams (executor/overlap_executor.py)
         self.staged_prompt_cache = sep_prompt_token and (staged_prompt_cache or token_pools > 1)
         if sep_prompt_token:
             self.num_prompt_workers = self.world_size

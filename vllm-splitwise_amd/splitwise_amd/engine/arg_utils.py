@@ -32,6 +32,7 @@ class EngineArgs:
     prefill_batch_tokens: int = 0
     prefill_max_wait: float = 0.1
     pipeline_steps: bool = False     # launch step n+1 before step n's tokens reach the host (co-located engine)
+    overlap_prompt_decode: bool = False  # one GPU: prompt steps beside the decode steps, on a stream of their own
     quantization: Optional[str] = None
     enforce_eager: bool = False
     max_context_len_to_capture: Optional[int] = None
@@ -61,9 +62,17 @@ class EngineArgs:
         cache_config = CacheConfig(self.block_size, self.gpu_memory_utilization, self.swap_space,
                                    self.kv_cache_dtype, model_config.get_sliding_window(),
                                    self.enable_prefix_caching)
+        if self.overlap_prompt_decode:
+            # the engine runs its split loop (a prompt side and a token side that run free of each other) over ONE
+            # worker: executor/overlap_executor.py
+            if (self.sep_prompt_token or self.tensor_parallel_size != 1 or self.token_pools != 1
+                    or self.staged_prompt_cache or not self.pipeline_steps):
+                raise ValueError("overlap_prompt_decode is a one-GPU option: it needs pipeline_steps and excludes "
+                                 "sep_prompt_token, tensor parallelism, token_pools and staged_prompt_cache")
         parallel_config = ParallelConfig(self.pipeline_parallel_size, self.tensor_parallel_size,
-                                         self.sep_prompt_token, self.disable_custom_all_reduce,
-                                         self.token_pools, self.staged_prompt_cache)
+                                         self.sep_prompt_token or self.overlap_prompt_decode,
+                                         self.disable_custom_all_reduce, self.token_pools, self.staged_prompt_cache)
+        parallel_config.one_gpu_overlap = self.overlap_prompt_decode
         if parallel_config.staged_prompt_cache and self.enable_prefix_caching:
             raise NotImplementedError("prefix caching needs the prompt pool to keep its blocks: it cannot be "
                                       "combined with staged_prompt_cache / token_pools > 1")

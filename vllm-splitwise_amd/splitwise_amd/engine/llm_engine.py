@@ -41,7 +41,10 @@ class LLMEngine:
             self.model_executor = executor
         else:
             if executor_class is None:
-                if parallel_config.tensor_parallel_size > 1:
+                if getattr(parallel_config, "one_gpu_overlap", False):
+                    from ..executor.overlap_executor import OverlapExecutor
+                    executor_class = OverlapExecutor
+                elif parallel_config.tensor_parallel_size > 1:
                     from ..executor.pool_executor import PoolExecutor
                     executor_class = PoolExecutor
                 elif parallel_config.world_size > 1:

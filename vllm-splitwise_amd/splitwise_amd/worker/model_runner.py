@@ -293,11 +293,13 @@ class ModelRunner:
     @torch.inference_mode()
     def execute_model(self, metas: List[SequenceGroupMetadata], kv_caches, blocks_to_nw=None,
                       prompt_layout: str = "packed", defer: bool = False, nw_peer: int = 0,
-                      share_samples: Optional[bool] = None):
+                      share_samples: Optional[bool] = None, track_pending: bool = True):
         """``defer``: return the step's ``PendingSamples`` (tokens still on the device) instead of a
         ``SamplerOutput``; the next decode step takes unknown last tokens from it.  ``share_samples``
         (tensor-parallel pools; default: whenever ``defer``): send the sampled ids to the pool's other ranks,
-        which must all make this call the same way -- off for a prompt pool, whose ranks never decode."""
+        which must all make this call the same way -- off for a prompt pool, whose ranks never decode.
+        ``track_pending`` off: the step's samples are not what the next decode step continues from (a prompt step
+        that runs beside the decode steps, on a stream of its own)."""
         is_prompt = metas[0].is_prompt
         restore = None
         if is_prompt:
@@ -331,7 +333,8 @@ class ModelRunner:
             result = self._share_sampled_ids(result, sampling_md)
         if not is_prompt and restore is not None and result is not None:
             result.reorder(restore[1])           # report in the order the step was asked for
-        self.pending = result if defer else None
+        if track_pending:
+            self.pending = result if defer else None
         return result
 
     def _share_sampled_ids(self, result, sampling_md: SamplingMetadata):

@@ -204,7 +204,8 @@ class Worker:
                       blocks_to_swap_out: Optional[Dict[int, int]] = None,
                       blocks_to_copy: Optional[Dict[int, List[int]]] = None,
                       blocks_to_nw: Optional[Dict[int, List[Tuple[int, int]]]] = None,
-                      nw_epochs: Optional[Dict[int, int]] = None, defer: bool = False, nw_peer: int = 0):
+                      nw_epochs: Optional[Dict[int, int]] = None, defer: bool = False, nw_peer: int = 0,
+                      track_pending: bool = True):
         """``defer`` leaves the sampled tokens on the device (see ModelRunner.execute_model).
         ``nw_epochs`` (optional) gives the hand-off count of every slot in ``blocks_to_nw`` as the
         engine counts it; without it each side counts its own signals / waits.  ``nw_peer`` (prompt
@@ -221,7 +222,8 @@ class Worker:
                 comm.wait(sem_id, nw_epochs.get(sem_id))
         output = self.model_runner.execute_model(seq_group_metadata_list, self.gpu_cache, blocks_to_nw, defer=defer,
                                                  nw_peer=nw_peer,
-                                                 share_samples=defer and not self.is_prompt_worker())
+                                                 share_samples=defer and not self.is_prompt_worker(),
+                                                 track_pending=track_pending)
         if blocks_to_nw and comm is not None and self.is_prompt_worker() and is_prompt:
             for sem_id in blocks_to_nw:
                 if nw_peer:
