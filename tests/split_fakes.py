@@ -177,11 +177,14 @@ class FakeWorker:
         return [int(self.cache[block_table[i // self.block_size], i % self.block_size]) for i in range(n)]
 
     def execute_model(self, seq_group_metadata_list=None, blocks_to_swap_in=None, blocks_to_swap_out=None,
-                      blocks_to_copy=None, blocks_to_nw=None, nw_epochs=None, defer=False, nw_peer=0):
+                      blocks_to_copy=None, blocks_to_nw=None, nw_epochs=None, defer=False, nw_peer=0,
+                      track_pending=True):
         out = self._execute(seq_group_metadata_list, blocks_to_nw, nw_epochs, nw_peer)
         # like the device, this worker remembers the tokens it sampled last: a deferred step's tokens
         # reach the engine one call later, and the next command names them by a placeholder (-1)
-        self._last_samples = {g.samples[0].parent_seq_id: g.samples[0].output_token for g in out}
+        # (track_pending off: a prompt step that runs beside the decode steps of the same worker)
+        if track_pending:
+            self._last_samples = {g.samples[0].parent_seq_id: g.samples[0].output_token for g in out}
         return _Deferred(out) if defer else out
 
     def _execute(self, seq_group_metadata_list, blocks_to_nw, nw_epochs, nw_peer=0) -> SamplerOutput:

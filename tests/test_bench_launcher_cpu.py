@@ -32,7 +32,9 @@ def test_leg_plans():
     import conftest  # noqa: F401
     from splitwise_amd.executor.bench_launch import build_plan
     plan = {leg["name"]: leg for leg in build_plan(8)}
-    assert list(plan) == ["pairs", "colocated", "asymmetric", "70b_tp4_pools", "70b_tp4_colocated"]
+    assert list(plan) == ["pairs", "colocated", "asymmetric", "colocated_overlap", "70b_tp4_pools", "70b_tp4_colocated"]
+    assert all(r["overlap"] for r in plan["colocated_overlap"]["replicas"])
+    assert plan["colocated_overlap"]["layout"] == "8x(co-located, prompt beside decode)"
     assert [r["devices"] for r in plan["pairs"]["replicas"]] == [[0, 1], [2, 3], [4, 5], [6, 7]]
     assert [r["devices"] for r in plan["asymmetric"]["replicas"]] == [[0, 1, 2], [3, 4, 5], [6, 7]]
     assert plan["asymmetric"]["layout"] == "2x(1P+2D) + 1P+1D"
@@ -59,16 +61,18 @@ def test_plain_python_launch_prints_one_line_with_every_leg(n):
     assert line["n_gpus"] == n and line["value"] > 0 and line["scaling"] == "weak"
     assert line["metric"].startswith("goodput") and line["unit"] == "tok/s"
     legs = line["legs"]
-    expected = {2: {"pairs", "colocated"},
-                4: {"pairs", "colocated", "asymmetric", "13b_gptq_fp8_tp2_pools", "13b_gptq_fp8_pairs",
-                    "13b_gptq_fp8_colocated"},
-                8: {"pairs", "colocated", "asymmetric", "70b_tp4_pools", "70b_tp4_colocated"}}[n]
+    expected = {2: {"pairs", "colocated", "colocated_overlap"},
+                4: {"pairs", "colocated", "asymmetric", "colocated_overlap", "13b_gptq_fp8_tp2_pools",
+                    "13b_gptq_fp8_pairs", "13b_gptq_fp8_colocated"},
+                8: {"pairs", "colocated", "asymmetric", "colocated_overlap", "70b_tp4_pools", "70b_tp4_colocated"}}[n]
     assert set(legs) == expected
     for name, leg in legs.items():
         assert "error" not in leg and "skipped" not in leg, (name, leg)
         assert leg["n_gpus"] == n and leg["value"] > 0 and leg["steady_state"], (name, leg)
         if "colocated" not in name:
             assert leg["vs_colocated"] > 0 and leg["kv_bytes_pushed"] > 0, (name, leg)
+        if name == "colocated_overlap":
+            assert leg["vs_colocated"] > 0 and leg["kv_bytes_pushed"] == 0 and leg["pipelined"], leg
     assert line["vs_colocated"] == legs["pairs"]["vs_colocated"]
     assert line["config"]["parallelism"] == {2: "1P+1D", 4: "2x(1P+1D)", 8: "4x(1P+1D)"}[n]
 
@@ -103,7 +107,7 @@ def test_headline_falls_back_to_the_runtime_transport_and_then_to_the_colocated_
     assert len(lines) == 1, (lines, proc.stderr[-2000:])
     line = json.loads(lines[0])
     assert proc.returncode == 0 and line["value"] > 0
-    assert list(line["legs"]) == ["pairs", "pairs_runtime_transport", "colocated"]
+    assert list(line["legs"]) == ["pairs", "pairs_runtime_transport", "colocated", "colocated_overlap"]
     assert "error" in line["legs"]["pairs"] and line["legs"]["pairs_runtime_transport"]["value"] == line["value"]
     assert line["config"]["headline_leg"] == "pairs_runtime_transport" and line["config"]["kv_transport"] == "runtime"
     assert "pairs) failed" in line["error"] and line["vs_colocated"] > 0

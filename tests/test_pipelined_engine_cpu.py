@@ -245,3 +245,49 @@ def test_abort_during_a_running_prompt_step_keeps_its_blocks_until_the_step_has_
         want[rid] = seq[len(prompt):]
     assert final == want
     assert bm.get_num_free_gpu_blocks() == 8
+
+
+@pytest.mark.parametrize("blocks", [64, 2])
+def test_overlap_executor_runs_the_split_loop_over_one_worker(blocks, tmp_path, monkeypatch):
+    """``overlap_prompt_decode`` on CPU: the engine's pipelined split loop over executor/overlap_executor.py with a
+    stand-in worker (no streams: the two sides' steps run in turn).  The stand-in computes every token from what its
+    cache holds and looks placeholders up in the samples of the last DECODE step, so a prompt step that disturbed
+    them, a decode step ahead of its prompt or a block handed out too early gives a wrong token.  The small cache
+    (the stand-in offers 16 blocks more than asked for: 18) forces preemption and recomputation."""
+    import random
+
+    from split_fakes import VOCAB, FakeWorker, next_token
+    from splitwise_amd import EngineArgs, LLMEngine, SamplingParams
+    from splitwise_amd.executor.overlap_executor import OverlapExecutor
+    monkeypatch.setenv("SPLIT_FAKE_DIR", str(tmp_path))
+    monkeypatch.setenv("SPLIT_FAKE_BLOCKS", str(blocks))
+    args = EngineArgs(model="llama-tiny", max_num_seqs=6, max_model_len=128, max_num_batched_tokens=512,
+                      swap_space=0.001, pipeline_steps=True, overlap_prompt_decode=True)
+    mc, cc, pc, sc, dc = args.create_engine_configs()
+    assert pc.sep_prompt_token and pc.one_gpu_overlap and pc.world_size == 2
+    executor = OverlapExecutor(mc, cc, pc, sc, dc, worker_cls=FakeWorker)
+    engine = LLMEngine(mc, cc, pc, sc, dc, executor=executor)
+    assert engine.pipeline_split and executor.driver_worker.mixed
+    rng = random.Random(1)
+    prompts = {str(i): [rng.randrange(VOCAB) for _ in range(rng.choice([1, 5, 16, 17, 40, 60]))] for i in range(14)}
+    lens = {rid: rng.choice([1, 2, 9, 30, 40]) for rid in prompts}
+    pending, finished, steps = list(prompts), {}, 0
+    while pending or engine.has_unfinished_requests():
+        if pending and steps % 2 == 0:
+            rid = pending.pop(0)
+            engine.add_request(rid, None, SamplingParams(temperature=0.0, max_tokens=lens[rid], ignore_eos=True),
+                               prompt_token_ids=prompts[rid])
+        for out in engine.step():
+            if out.finished:
+                finished[out.request_id] = list(out.outputs[0].token_ids)
+        steps += 1
+        assert steps < 3000
+    for rid, prompt in prompts.items():
+        seq = list(prompt)
+        for _ in range(lens[rid]):
+            seq.append(next_token(seq))
+        assert finished[rid] == seq[len(prompt):], rid
+    assert engine.scheduler.block_manager.get_num_free_gpu_blocks() == cc.num_gpu_blocks
+    assert (getattr(engine.scheduler, "num_preemptions", 0) > 0) == (blocks == 2)
+    with pytest.raises(ValueError):
+        EngineArgs(model="llama-tiny", overlap_prompt_decode=True).create_engine_configs()       # needs pipeline_steps

@@ -69,6 +69,8 @@ def _describe(replicas: List[Dict[str, Any]]) -> str:
         tp = r.get("tp", 1)
         if r["kind"] == "colocated":
             tag = "co-located" if tp == 1 else f"TP{tp} co-located"
+            if r.get("overlap"):
+                tag += ", prompt beside decode"
         else:
             pools = r.get("token_pools", 1)
             tag = f"1P+{pools}D" if tp == 1 else (f"TP{tp}+TP{tp}" if pools == 1 else f"TP{tp}+{pools}xTP{tp}")
@@ -88,6 +90,10 @@ def build_plan(n: int, model: str = "llama-2-7b", dtype: str = "bfloat16", legs:
     if n >= 3:
         plan.append({"name": "asymmetric", "role": "extra", "of": "pairs",
                      "replicas": _trios_layout(n, model, dtype, **base)})
+    # the co-located replicas once more with prompt steps BESIDE their decode steps (EngineArgs.overlap_prompt_decode):
+    # the best one GPU does by itself, for the split legs to be held against
+    plan.append({"name": "colocated_overlap", "role": "extra", "of": "pairs",
+                 "replicas": [_replica("colocated", [i], model, dtype, overlap=True, **base) for i in range(n)]})
     q13 = dict(quantization="gptq", kv_cache_dtype="fp8_e5m2")
     if n == 4:
         # (the tensor-parallel leg last: should a pool hang on its first run over real links, the legs before it

@@ -68,12 +68,20 @@ def build_engine(spec: Dict[str, Any]):
         enforce_eager=spec.get("enforce_eager", False), max_context_len_to_capture=1024,
         prefill_batch_tokens=spec["prefill_batch_tokens"], prefill_max_wait=spec["prefill_max_wait"],
         pipeline_steps=spec.get("pipeline_steps", True), token_pools=spec.get("token_pools", 1),
+        overlap_prompt_decode=bool(spec.get("overlap")) and not split and tp == 1,
         # a prompt pool keeps only the prompts in flight (the reference's same-numbering layout would hold a second
         # full cache on the prompt GPUs for nothing); SPLITWISE_BENCH_REFERENCE_LAYOUT=1 measures that layout
         staged_prompt_cache=split and spec.get("pipeline_steps", True)
         and os.environ.get("SPLITWISE_BENCH_REFERENCE_LAYOUT") != "1")
     mc, cc, pc, sc, dc = args.create_engine_configs()
     devices = list(spec["devices"])
+    if pc.one_gpu_overlap:
+        from .overlap_executor import OverlapExecutor
+        worker_cls = _worker_cls(spec)
+        extra = {"worker_cls": worker_cls} if worker_cls is not None else {}
+        executor = OverlapExecutor(mc, cc, pc, sc, dc, num_gpu_blocks_override=args.num_gpu_blocks_override,
+                                   device_index=devices[0], **extra)
+        return LLMEngine(mc, cc, pc, sc, dc, executor=executor), executor
     if len(devices) != pc.world_size:
         raise ValueError(f"replica of kind {spec['kind']} with tp={tp} needs {pc.world_size} devices, got {devices}")
     worker_cls = _worker_cls(spec)

@@ -35,23 +35,30 @@ class OverlapExecutor(GPUExecutor):
         super().__init__(model_config, cache_config, local, scheduler_config, device_config,
                          num_gpu_blocks_override, device_index, worker_cls)
         self.parallel_config = parallel_config
-        device = torch.device("cuda", device_index)
-        self.prompt_stream = torch.cuda.Stream(device)
-        self.decode_stream = torch.cuda.Stream(device)
+        # (CPU stand-in workers -- dry runs of the benchmark launcher -- have no streams: their steps run in turn)
+        self.prompt_stream = self.decode_stream = None
+        if torch.cuda.is_available():
+            device = torch.device("cuda", device_index)
+            self.prompt_stream = torch.cuda.Stream(device)
+            self.decode_stream = torch.cuda.Stream(device)
         self._previous = None          # the decode step in flight
         self._collectable = None       # the one before it
 
     def execute_split(self, prompt_kwargs, decode_kwargs):
         raise NotImplementedError("OverlapExecutor serves the pipelined split loop only (pipeline_steps=True)")
 
-    def _run(self, stream: "torch.cuda.Stream", kwargs: Dict[str, Any], track_pending: bool):
+    def _run(self, stream: Optional["torch.cuda.Stream"], kwargs: Dict[str, Any], track_pending: bool):
+        call = dict(seq_group_metadata_list=kwargs["seq_group_metadata_list"],
+                    blocks_to_swap_in=kwargs.get("blocks_to_swap_in") or {},
+                    blocks_to_swap_out=kwargs.get("blocks_to_swap_out") or {},
+                    blocks_to_copy=kwargs.get("blocks_to_copy") or {}, blocks_to_nw={}, defer=True,
+                    track_pending=track_pending)
+        if stream is None:
+            return self.driver_worker.execute_model(**call)
         # everything issued so far (weights, cache set-up, the other side's finished steps) is visible to the stream
         stream.wait_stream(torch.cuda.current_stream(stream.device))
         with torch.cuda.stream(stream):
-            return self.driver_worker.execute_model(
-                kwargs["seq_group_metadata_list"], kwargs.get("blocks_to_swap_in") or {},
-                kwargs.get("blocks_to_swap_out") or {}, kwargs.get("blocks_to_copy") or {}, {}, defer=True,
-                track_pending=track_pending)
+            return self.driver_worker.execute_model(**call)
 
     def launch_prompt(self, kwargs: Dict[str, Any], lane: int = 0):
         # (its samples are not what the next decode step continues from: track_pending off)
@@ -63,7 +70,8 @@ class OverlapExecutor(GPUExecutor):
         if kwargs and (kwargs.get("blocks_to_swap_in") or kwargs.get("blocks_to_swap_out") or kwargs.get("blocks_to_copy")):
             # blocks moved or copied by this step may be handed to the next prompt: its stream waits for them
             # (rare: single-sequence groups are preempted by recomputation)
-            self.prompt_stream.wait_stream(self.decode_stream)
+            if self.prompt_stream is not None:
+                self.prompt_stream.wait_stream(self.decode_stream)
 
     def decode_collect(self, lane: int = 0):
         pending, self._collectable = self._collectable, None
