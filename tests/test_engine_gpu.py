@@ -137,16 +137,20 @@ def test_opt_125m_geometry_greedy_generation_matches_cpu_model():
         torch.cuda.empty_cache()
 
 
-@pytest.mark.parametrize("sep,pipeline", [(False, False), (False, True), (True, False)])
+@pytest.mark.parametrize("sep,pipeline", [(False, False), (False, True), (True, False), ("overlap", True)])
 def test_prefix_caching_reuses_blocks_and_generates_like_the_cpu_model(sep, pipeline, monkeypatch):
     """enable_prefix_caching: prompts that start with the same tokens share KV blocks; once those are computed a
     later prompt runs only its remaining tokens, through the prefix-aware prompt kernel over the paged
     context.  The tokens must still be the CPU model's (which knows nothing of caches), co-located, with
-    pipelined steps, and with a prompt worker pushing to a token worker."""
+    pipelined steps, with a prompt worker pushing to a token worker, and with prompt steps beside decode steps on
+    one GPU ("overlap")."""
     from splitwise_amd import LLM, SamplingParams, _C
     random.seed(7)
+    overlap = sep == "overlap"
+    sep = sep is True
     llm = LLM("llama-tiny", enable_prefix_caching=True, enforce_eager=True, num_gpu_blocks_override=96,
-              max_num_seqs=8, max_model_len=512, swap_space=0.01, sep_prompt_token=sep, pipeline_steps=pipeline)
+              max_num_seqs=8, max_model_len=512, swap_space=0.01, sep_prompt_token=sep, pipeline_steps=pipeline,
+              overlap_prompt_decode=overlap)
     calls = {"prefix": 0}
     orig = _C.ops.context_attention_fwd
 
@@ -179,17 +183,20 @@ def test_prefix_caching_reuses_blocks_and_generates_like_the_cpu_model(sep, pipe
 
 
 @pytest.mark.parametrize("quantization", ["gptq", "awq"])
-def test_int4_models_match_cpu_model(quantization):
+@pytest.mark.parametrize("overlap", [False, True])
+def test_int4_models_match_cpu_model(quantization, overlap):
     """Llama geometry with every linear layer in int4 (random words, group size 128): the engine's
-    dequant-GEMM path against the CPU model run on the reconstructed fp16 weights."""
+    dequant-GEMM path against the CPU model run on the reconstructed fp16 weights -- also with prompt steps beside
+    the decode steps on a second stream (the fused GEMMs keep one workspace per stream)."""
     from splitwise_amd import LLM, SamplingParams
     random.seed(2)
-    llm = LLM("llama-tiny", quantization=quantization, enforce_eager=True, num_gpu_blocks_override=128,
-              max_num_seqs=8, max_model_len=512, swap_space=0.01)
+    llm = LLM("llama-tiny", quantization=quantization, enforce_eager=not overlap, num_gpu_blocks_override=128,
+              max_num_seqs=8, max_model_len=512, swap_space=0.01, pipeline_steps=overlap,
+              overlap_prompt_decode=overlap, kv_cache_dtype="fp8_e5m2" if overlap else "auto")
     vocab = llm.llm_engine.model_config.get_vocab_size()
     prompts = [[random.randrange(vocab) for _ in range(n)] for n in (5, 33, 64, 17, 300, 1)]
     outs = llm.generate(prompt_token_ids=prompts, sampling_params=SamplingParams(temperature=0.0, max_tokens=12))
-    _check_greedy(llm, prompts, outs, tol=3e-2)
+    _check_greedy(llm, prompts, outs, tol=8e-2 if overlap else 3e-2)        # (an fp8 cache costs precision)
     del llm
     torch.cuda.empty_cache()
 
