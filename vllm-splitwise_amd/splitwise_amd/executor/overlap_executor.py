@@ -9,7 +9,6 @@ step has finished on the device.  What the two streams buy: a prompt step is bou
 step by HBM, and side by side they take less time than one after the other (the reference has no counterpart;
 its scheduler emits either a prompt step or a decode step, vllm/core/scheduler.py:168-340).
 """
-import copy
 from typing import Any, Dict, Optional
 
 import torch
