@@ -4,7 +4,11 @@
   python bench.py [--gpus N] [--steps K] [--warmup W]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (same result)
 
-N = 1  co-located serving on one MI355X (the configuration the metric is quoted on).
+N = 1  co-located serving on one MI355X (the configuration the metric is quoted on).  The engine runs its
+       prompt steps BESIDE its decode steps, on a second stream of the one GPU
+       (EngineArgs.overlap_prompt_decode; every timed step is then a decode step with prompt work going on
+       next to it); --plain-engine lets the two kinds of step take turns as the reference's scheduler emits
+       them, and the default run times that engine too, in a child process, and reports it as "plain_engine".
 N > 1  this process becomes a launcher that never touches a GPU and starts every engine as a fresh
        child process (splitwise_amd/executor/bench_launch.py; under torchrun rank 0 is the launcher
        and the other ranks leave at once).  Headline leg: N/2 independent (prompt GPU, token GPU)
@@ -38,7 +42,8 @@ region actually held (live requests, decode batch sizes, prompt / decode steps) 
 The JSON line also carries
   roofline      decode paged attention (the dominant, HBM-bound kernel): algorithmic KV bytes
                 per launch / average launch time, timed with HIP events on the launch stream
-                over decode batches sampled from the timed region;
+                over decode batches sampled from the timed region (launched alone, after the region: inside an
+                overlapped step the kernel shares the GPU with a prompt step's kernels);
   cpu_baseline  the CPU oracle (torch restatement of the same model and operators) timed on the
                 host cores on a bounded sample, scaled to tok/s.
 """
@@ -86,9 +91,13 @@ def parse_args():
     ap.add_argument("--dtype", default=None, help="activation dtype (default bf16, fp16 with --quantization)")
     ap.add_argument("--enforce-eager", action="store_true")
     ap.add_argument("--overlap-prompt-decode", action="store_true",
-                    help="N = 1: prompt steps and decode steps on two streams of the one GPU (OverlapExecutor)")
-    ap.add_argument("--no-overlap-leg", action="store_true",
-                    help="N = 1: do not time the same workload once more with --overlap-prompt-decode (a child process)")
+                    help="N = 1 (the default there): prompt steps beside the decode steps, on a second stream of the "
+                         "one GPU (EngineArgs.overlap_prompt_decode)")
+    ap.add_argument("--plain-engine", action="store_true",
+                    help="N = 1: prompt steps and decode steps take turns, as the reference's scheduler emits them "
+                         "(implied by --no-pipeline-steps)")
+    ap.add_argument("--no-overlap-leg", "--no-other-engine-leg", dest="no_overlap_leg", action="store_true",
+                    help="N = 1: do not time the same workload once more on the other engine (a child process)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--window-trace", type=int, default=0,
@@ -371,6 +380,8 @@ def main():
         from splitwise_amd.executor import bench_launch
         sys.exit(bench_launch.main(args))
 
+    args.overlap_prompt_decode = not (args.plain_engine or args.no_pipeline_steps)
+
     def run_single() -> dict:
         """The timed run itself; everything it builds (engine, cache, graphs) dies with its frame."""
         from splitwise_amd import EngineArgs, LLMEngine
@@ -508,23 +519,25 @@ def main():
     print(f"after the timed run: {torch.cuda.mem_get_info()[0] / 2**30:.1f} GiB of device memory free, "
           f"{torch.cuda.memory_allocated() / 2**30:.2f} GiB still allocated by this process, "
           f"{torch.cuda.memory_reserved() / 2**30:.2f} GiB reserved", file=sys.stderr, flush=True)
-    if not (args.overlap_prompt_decode or args.no_overlap_leg or args.no_fill):
-        result["overlap_prompt_decode"] = overlap_leg(args, result["value"])
+    if not (args.no_overlap_leg or args.no_fill or args.no_pipeline_steps):
+        # the same workload on the other engine, beside the headline
+        result["plain_engine" if args.overlap_prompt_decode else "overlap_prompt_decode"] = \
+            other_engine_leg(args, result["value"])
     if not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args.model, args.prompt_len, args.decode_len)
     print(json.dumps(result))
 
 
-def overlap_leg(args, default_value: float) -> dict:
-    """The same workload once more with the engine's ``overlap_prompt_decode`` option, in a child process of its
-    own (this process keeps its engine; the option's figure is reported beside the headline, never as it: the
-    headline's roofline is about kernels that have the GPU to themselves).  Whatever happens to the child, the
-    line of this process is printed."""
+def other_engine_leg(args, this_value: float) -> dict:
+    """The same workload once more on the other engine -- prompt and decode steps taking turns when this run had
+    them side by side, and the other way round -- in a child process of its own.  Whatever happens to the child,
+    the line of this process is printed."""
     import subprocess
     preload = os.environ.get("LD_PRELOAD", "")
     if "rocprof" in preload or "ROCP_TOOL_LIBRARIES" in os.environ:
         return {"skipped": "under a profiler: a second engine's kernels would land in the same trace"}
-    cmd = [sys.executable, os.path.abspath(__file__), "--overlap-prompt-decode", "--no-cpu-baseline", "--no-roofline",
+    other = "--plain-engine" if args.overlap_prompt_decode else "--overlap-prompt-decode"
+    cmd = [sys.executable, os.path.abspath(__file__), other, "--no-overlap-leg", "--no-cpu-baseline", "--no-roofline",
            "--steps", str(args.steps), "--warmup", str(args.warmup), "--concurrency", str(args.concurrency),
            "--model", args.model, "--prompt-len", str(args.prompt_len), "--decode-len", str(args.decode_len),
            "--max-num-batched-tokens", str(args.max_num_batched_tokens),
@@ -545,9 +558,11 @@ def overlap_leg(args, default_value: float) -> dict:
         keep = ("value", "ms_per_step", "slo_attainment", "ttft_p50_ms", "ttft_p99_ms", "tpot_p50_ms", "tpot_p99_ms")
         out = {k: line.get(k) for k in keep}
         out["steady_state"] = line["config"].get("steady_state")
-        out["vs_default"] = round(line["value"] / max(default_value, 1e-9), 4)
-        out["what"] = ("prompt steps beside the decode steps on a second stream of the same GPU "
-                       "(EngineArgs.overlap_prompt_decode), same workload and SLO, timed in a child process")
+        out["vs_headline"] = round(line["value"] / max(this_value, 1e-9), 4)
+        out["what"] = (("prompt steps and decode steps taking turns (the reference's scheduling; pipelined steps and "
+                        "prefill batching as in the headline run)" if args.overlap_prompt_decode else
+                        "prompt steps beside the decode steps on a second stream of the same GPU "
+                        "(EngineArgs.overlap_prompt_decode)") + ", same workload and SLO, timed in a child process")
         return out
     except (subprocess.TimeoutExpired, OSError, ValueError, KeyError) as exc:
         return {"error": repr(exc)[:400]}

@@ -1,6 +1,6 @@
 #!/bin/bash
 # The driver's bench command under rocprofv3 --kernel-trace --stats: the JSON line, the per-kernel summary and the
-# averages over the timed window, all under gpurun_out/prof_latest/.
+# averages over the timed window, all under gpurun_out/prof_latest/ (extra arguments go to bench.py).
 set -e
 R=$PWD
 O=$R/gpurun_out/prof_latest
@@ -8,7 +8,7 @@ rm -rf $O && mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 (while sleep 30; do echo tick; done) &
 T=$!
-timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o bench -- python3 $R/bench.py --steps 20 --warmup 5 > $O/bench_under_rocprof.log 2> $O/rocprof.err || { kill $T; tail -n 20 $O/rocprof.err; exit 1; }
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o bench -- python3 $R/bench.py --steps 20 --warmup 5 "$@" > $O/bench_under_rocprof.log 2> $O/rocprof.err || { kill $T; tail -n 20 $O/rocprof.err; exit 1; }
 kill $T
 cd $R
 trap 'rm -rf $O/trace' EXIT

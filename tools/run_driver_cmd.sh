@@ -14,6 +14,6 @@ python - <<'P'
 import json
 d = json.load(open("gpurun_out/bench_driver_final.json"))
 print(d["value"], d["ms_per_step"], d["roofline"]["frac"], d["cpu_baseline"]["value"])
-print(d["overlap_prompt_decode"])
+print(d.get("plain_engine") or d.get("overlap_prompt_decode"))
 P
 exit $rc
