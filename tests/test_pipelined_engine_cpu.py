@@ -217,13 +217,14 @@ def test_abort_during_a_running_prompt_step_keeps_its_blocks_until_the_step_has_
     seq_b = [g for g in engine.scheduler.running if g.request_id == "b"][0].get_seqs()[0]
     blocks_b = set(bm.get_block_table(seq_b))
     assert len(blocks_b) == 3 and not (blocks_b & blocks_a) and bm.get_num_free_gpu_blocks() == 2
-    # a third prompt has to wait: two prompt steps are in flight
+    # a third prompt has to wait: two prompt steps are in flight.  The call has nothing else to do, so it waits
+    # for the older one (a's), and what has finished by the end of a call is collected in that call: a's result
+    # is dropped and only now do its blocks come back
     engine.add_request("c", None, params, prompt_token_ids=list(range(200, 210)))
-    engine.step()
-    assert ex.prompt_pending is second and bm.get_num_free_gpu_blocks() == 2
-    pending.finished = True                                                        # the first step ends on the GPU
-    outs = engine.step()                                                           # resolved, dropped; c is launched
+    outs = engine.step()
     assert all(o.request_id != "a" for o in outs)
+    assert ex.prompt_pending is second and pending.finished and bm.get_num_free_gpu_blocks() == 5
+    engine.step()                                                                  # c is launched
     assert ex.prompt_pending is not second
     assert bm.get_num_free_gpu_blocks() == 8 - 3 - 1                               # a's blocks came back; b and c hold theirs
     second.finished = True

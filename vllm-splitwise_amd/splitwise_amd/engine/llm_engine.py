@@ -444,17 +444,8 @@ class LLMEngine:
         ex = self.model_executor
         lanes = len(self.schedulers)
         outputs: List[RequestOutput] = []
-        progressed = False
         # ---- prompt pool
-        while self._prompt_queue and self._prompt_queue[0][0].done():          # in launch order
-            pending, outs_p, ids, lane = self._prompt_queue.popleft()
-            sampled = pending.resolve()
-            live = [(g, o) for g, o in zip(outs_p.scheduled_seq_groups, sampled)
-                    if g.get_seqs(status=SequenceStatus.RUNNING)]              # not aborted meanwhile
-            outputs += self._process_model_outputs(SamplerOutput([o for _, o in live]), outs_p,
-                                                   groups=[g for g, _ in live], lane=lane)
-            self.schedulers[lane].prompt_step_done(ids)
-            progressed = True
+        progressed = self._collect_finished_prompt_steps(outputs)
         if len(self._prompt_queue) < self._prompt_queue_depth:
             for turn in range(lanes):
                 lane = (self._next_prompt_lane + turn) % lanes
@@ -511,8 +502,27 @@ class LLMEngine:
             progressed = True
         if not progressed and self._prompt_queue:
             self._prompt_queue[0][0].wait()                    # nothing else to do: wait for the oldest prompt step
+        # a prompt step that finished while this call sat in the token pools' collect is reported now, not a whole
+        # decode step later: its first tokens are that much earlier with the caller (its sequences join the decode
+        # batch at the next call either way)
+        self._collect_finished_prompt_steps(outputs)
         self.scheduler.release_held()                          # aborted sequences whose last step has resolved
         return outputs
+
+    def _collect_finished_prompt_steps(self, outputs: List[RequestOutput]) -> bool:
+        """Resolves the prompt steps at the head of the queue that have finished on the device, in launch order;
+        appends their requests' outputs.  -> whether there was one."""
+        found = False
+        while self._prompt_queue and self._prompt_queue[0][0].done():
+            pending, outs_p, ids, lane = self._prompt_queue.popleft()
+            sampled = pending.resolve()
+            live = [(g, o) for g, o in zip(outs_p.scheduled_seq_groups, sampled)
+                    if g.get_seqs(status=SequenceStatus.RUNNING)]              # not aborted meanwhile
+            outputs += self._process_model_outputs(SamplerOutput([o for _, o in live]), outs_p,
+                                                   groups=[g for g, _ in live], lane=lane)
+            self.schedulers[lane].prompt_step_done(ids)
+            found = True
+        return found
 
     def _step_pipelined(self) -> List[RequestOutput]:
         metas, scheduler_outputs = self.scheduler.schedule()
