@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""The overlap engine (prompt steps beside decode steps on one GPU) against the plain co-located engine on random
+scenarios: arrivals while others decode, stop tokens, aborts at random moments, a cache small enough to preempt.
+Greedy tokens of every request that was not aborted must be identical; every block must come back.
+
+  python tools/overlap_stress.py [seeds]
+"""
+import random
+import sys
+
+sys.path[:0] = ["/root/repo", "/root/repo/vllm-splitwise_amd"]
+import torch  # noqa: E402
+from splitwise_amd import EngineArgs, LLMEngine, SamplingParams  # noqa: E402
+
+
+def scenario(seed):
+    rng = random.Random(seed)
+    blocks = rng.choice([48, 64, 96, 400])
+    reqs = []
+    for i in range(rng.randrange(60, 120)):
+        prompt = [rng.randrange(512) for _ in range(rng.choice([1, 2, 15, 16, 17, 31, 64, 100, 150]))]
+        reqs.append((str(i), prompt, rng.choice([1, 2, 5, 17, 30, 60]), rng.randrange(0, 150), rng.random() < 0.3))
+    aborts = {rid: arrival + rng.randrange(0, 20) for rid, _, _, arrival, _ in reqs if rng.random() < 0.15}
+    return blocks, reqs, aborts
+
+
+def run(seed, overlap, stops):
+    blocks, reqs, aborts = scenario(seed)
+    engine = LLMEngine.from_engine_args(EngineArgs(
+        model="llama-tiny", max_num_seqs=10, max_model_len=256, swap_space=0.01, num_gpu_blocks_override=blocks,
+        pipeline_steps=True, enforce_eager=False, overlap_prompt_decode=overlap, max_context_len_to_capture=256))
+    done, aborted, call = {}, set(), 0
+    while call < 170 or engine.has_unfinished_requests():
+        for rid, prompt, n, arrival, want_stop in reqs:
+            if arrival == call:
+                stop = [stops[rid]] if (want_stop and rid in stops) else []
+                engine.add_request(rid, None, SamplingParams(temperature=0.0, max_tokens=n, ignore_eos=True,
+                                                             stop_token_ids=stop), prompt_token_ids=prompt)
+        for rid, when in aborts.items():
+            if when == call and rid not in done:
+                engine.abort_request(rid)
+                aborted.add(rid)
+        for out in engine.step():
+            if out.finished:
+                done[out.request_id] = list(out.outputs[0].token_ids)
+        call += 1
+        assert call < 20000
+    free = engine.scheduler.block_manager.get_num_free_gpu_blocks()
+    pre = getattr(engine.scheduler, "num_preemptions", 0)
+    del engine
+    torch.cuda.empty_cache()
+    return done, aborted, free == blocks, pre
+
+
+bad = 0
+for seed in range(int(sys.argv[1]) if len(sys.argv) > 1 else 6):
+    base, _, _, _ = run(seed, False, {})
+    stops = {rid: toks[min(2, len(toks) - 1)] for rid, toks in base.items() if toks}
+    plain, ab_p, ok_p, pre_p = run(seed, False, stops)
+    over, ab_o, ok_o, pre_o = run(seed, True, stops)
+    common = [rid for rid in plain if rid in over and rid not in ab_p and rid not in ab_o]
+    diff = [rid for rid in common if plain[rid] != over[rid]]
+    print(f"seed {seed}: {len(common)} requests compared, {len(diff)} differ, blocks back: {ok_p} {ok_o}, "
+          f"preemptions {pre_p} / {pre_o}", flush=True)
+    bad += len(diff) + (not ok_p) + (not ok_o)
+sys.exit(1 if bad else 0)
