@@ -66,7 +66,8 @@ class OverlapExecutor(GPUExecutor):
     def decode_send(self, kwargs: Optional[Dict[str, Any]], lane: int = 0) -> None:
         self._collectable = self._previous
         self._previous = self._run(self.decode_stream, kwargs, track_pending=True) if kwargs else None
-        if kwargs and (kwargs.get("blocks_to_swap_in") or kwargs.get("blocks_to_swap_out") or kwargs.get("blocks_to_copy")):
+        moved = kwargs and any(kwargs.get(k) for k in ("blocks_to_swap_in", "blocks_to_swap_out", "blocks_to_copy"))
+        if moved:
             # blocks moved or copied by this step may be handed to the next prompt: its stream waits for them
             # (rare: single-sequence groups are preempted by recomputation)
             if self.prompt_stream is not None:
