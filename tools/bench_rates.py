@@ -87,6 +87,7 @@ def main():
     ap.add_argument("--prefill-batch-tokens", type=int, default=2300)
     ap.add_argument("--prefill-max-wait", type=float, default=0.08)
     ap.add_argument("--no-pipeline-steps", action="store_true")
+    ap.add_argument("--overlap-prompt-decode", action="store_true", help="prompt steps beside decode steps (two streams)")
     ap.add_argument("--quantization", default=None, choices=[None, "gptq", "awq"])
     ap.add_argument("--kv-cache-dtype", default="auto", choices=["auto", "fp8_e5m2"])
     args = ap.parse_args()
@@ -100,7 +101,8 @@ def main():
         model=args.model, dtype=dtype, quantization=args.quantization, kv_cache_dtype=args.kv_cache_dtype, max_num_seqs=args.max_num_seqs, max_model_len=2048, max_num_batched_tokens=4096,
         num_gpu_blocks_override=int(args.max_num_seqs * seq_blocks * 1.25) + 64, swap_space=0.25,
         max_context_len_to_capture=1024, prefill_batch_tokens=args.prefill_batch_tokens,
-        prefill_max_wait=args.prefill_max_wait, pipeline_steps=not args.no_pipeline_steps))
+        prefill_max_wait=args.prefill_max_wait, pipeline_steps=not args.no_pipeline_steps,
+        overlap_prompt_decode=args.overlap_prompt_decode))
     run_rate(engine, 8.0, 32, args.prompt_len, args.decode_len, args.temperature, 10 ** 6)      # warm-up
     first_id = 0
     for rate in [float(r) for r in args.rates.split(",")]:
@@ -109,7 +111,8 @@ def main():
         first_id += n
         res["config"] = (f"{args.model} {dtype}" + (f" {args.quantization} int4" if args.quantization else "") +
                          (" fp8 KV cache" if args.kv_cache_dtype != "auto" else "") +
-                         f" co-located, 1 GPU, prefill {args.prompt_len} / decode {args.decode_len}")
+                         f" co-located, 1 GPU, prefill {args.prompt_len} / decode {args.decode_len}" +
+                         (", prompt steps beside decode steps" if args.overlap_prompt_decode else ""))
         print(json.dumps(res), flush=True)
 
 
