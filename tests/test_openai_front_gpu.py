@@ -13,16 +13,18 @@ from tiny_tokenizer import build_tokenizer
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def served():
+@pytest.fixture(scope="module", params=["plain", "overlap"])
+def served(request):
+    """The front over the plain engine, and over the engine that runs prompt steps beside its decode steps."""
     from fastapi.testclient import TestClient
     from splitwise_amd import EngineArgs, LLMEngine
     from splitwise_amd.engine.async_llm_engine import AsyncLLMEngine
     from splitwise_amd.entrypoints.openai import api_server
     tok = build_tokenizer(512)                      # llama-tiny has 512 embedding rows
     assert len(tok) == 512
+    overlap = request.param == "overlap"
     args = EngineArgs(model="llama-tiny", max_num_seqs=8, max_model_len=512, swap_space=0.01,
-                      num_gpu_blocks_override=256)
+                      num_gpu_blocks_override=256, pipeline_steps=overlap, overlap_prompt_decode=overlap)
     engine = LLMEngine.from_engine_args(args, tokenizer=tok, log_stats=True)
     runner = engine.model_executor.driver_worker.model_runner
     sd = {k: v.detach().cpu() for k, v in runner.model.state_dict().items()}
