@@ -342,6 +342,34 @@ def test_pipelined_steps_generate_the_same_tokens(enforce_eager, blocks):
     assert results[0] == results[1]
 
 
+@pytest.mark.parametrize("prompt_len", [31, 48])
+def test_one_prompt_sampled_several_ways_under_prefix_caching_and_pipelined_steps(prompt_len):
+    """The same prompt in four requests with different seeds: their blocks are shared up to the first sampled
+    token and must part there.  With pipelined steps the block manager makes room for a token that is still on
+    the device; a block that fills up that way must not be addressed by content yet (all four would be given one
+    block and read each other's keys and values).  Plain engine without the cache, pipelined engine with it and
+    prompt steps beside decode steps with it: token for token the same."""
+    from splitwise_amd import LLM, SamplingParams
+    random.seed(9)
+    prompt = [random.randrange(512) for _ in range(prompt_len)]
+    results = []
+    for caching, pipeline, overlap in ((False, False, False), (True, True, False), (True, True, True)):
+        llm = LLM("llama-tiny", enforce_eager=not pipeline, num_gpu_blocks_override=128, max_num_seqs=8,
+                  max_model_len=256, swap_space=0.01, pipeline_steps=pipeline, enable_prefix_caching=caching,
+                  overlap_prompt_decode=overlap)
+        for i in range(4):
+            llm.llm_engine.add_request(str(i), None, SamplingParams(temperature=1.0, seed=20 + i, max_tokens=40,
+                                                                    ignore_eos=True), prompt_token_ids=prompt)
+        outs = llm._run_engine()
+        results.append([o.outputs[0].token_ids for o in outs])
+        assert llm.llm_engine.scheduler.block_manager.get_num_free_gpu_blocks() == 128
+        del llm
+        torch.cuda.empty_cache()
+    assert len({tuple(t) for t in results[0]}) == 4
+    assert results[1] == results[0]
+    assert results[2] == results[0]
+
+
 @pytest.mark.parametrize("pipeline,blocks", [(False, 256), (True, 256), (False, 24)])
 def test_parallel_sampling_forks_share_the_prompt_and_copy_on_write(pipeline, blocks):
     """n > 1 inside one request (vllm/engine/llm_engine.py:424-534, Scheduler.fork_seq, block_manager.py:302-309):

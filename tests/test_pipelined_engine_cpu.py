@@ -143,6 +143,108 @@ def test_pipelined_late_arrivals_and_abort():
     assert not engine.has_unfinished_requests()
 
 
+class _PerSequenceExecutor(FakeExecutor):
+    """Sampling with temperature: what a sequence gets next depends on the sequence, not only on its tokens."""
+
+    @staticmethod
+    def _sample(metas) -> SamplerOutput:
+        outs = []
+        for meta in metas:
+            (seq_id, data), = meta.seq_data.items()
+            ids = [t for t in data.get_token_ids() if t != PLACEHOLDER_TOKEN_ID]
+            tok = (next_token(ids) + 7 * seq_id) % VOCAB
+            outs.append(SequenceGroupOutput([SequenceOutput(seq_id, tok, {tok: Logprob(-0.5)})]))
+        return SamplerOutput(outs)
+
+    def execute_model(self, seq_group_metadata_list, blocks_to_swap_in, blocks_to_swap_out, blocks_to_copy,
+                      blocks_to_nw=None, defer=False):
+        if not defer:
+            return self._sample(seq_group_metadata_list)
+        pending = _Deferred(seq_group_metadata_list)
+        pending.resolve = lambda: self._sample(seq_group_metadata_list)
+        return pending
+
+
+def _blocks_shared_with_different_content(engine, block_size=16):
+    bm = engine.scheduler.block_manager
+    seqs = [g.get_seqs()[0] for g in engine.scheduler.running]
+    found = []
+    for i, a in enumerate(seqs):
+        for b in seqs[i + 1:]:
+            tables = bm.block_tables.get(a.seq_id, []), bm.block_tables.get(b.seq_id, [])
+            for k, (x, y) in enumerate(zip(*tables)):
+                if x != y:
+                    continue
+                ta, tb = ([t for t in s.get_token_ids()[block_size * k:block_size * (k + 1)]
+                           if t != PLACEHOLDER_TOKEN_ID] for s in (a, b))
+                n = min(len(ta), len(tb))
+                if ta[:n] != tb[:n]:
+                    found.append((k, x, a.seq_id, b.seq_id))
+    return found
+
+
+@pytest.mark.parametrize("prompt_len", [31, 32, 33, 47])
+def test_pipelined_prefix_caching_never_hashes_a_token_that_is_not_there_yet(prompt_len):
+    """The same prompt three times, sampled differently: a block that fills up while its newest token is still
+    on the device must not be addressed by a hash over the placeholder (all three would get one block)."""
+    def engine_for(pipeline):
+        args = EngineArgs(model="llama-tiny", max_num_seqs=4, max_model_len=256, max_num_batched_tokens=256,
+                          swap_space=0.001, pipeline_steps=pipeline, enable_prefix_caching=True)
+        mc, cc, pc, sc, dc = args.create_engine_configs()
+        cc.num_gpu_blocks, cc.num_cpu_blocks = 64, 8
+        return LLMEngine(mc, cc, pc, sc, dc, executor=_PerSequenceExecutor())
+
+    prompt = [(3 * j + 1) % VOCAB for j in range(prompt_len)]
+    results = {}
+    for pipeline in (False, True):
+        engine = engine_for(pipeline)
+        for i in range(3):
+            engine.add_request(f"r{i}", None, SamplingParams(temperature=1.0, max_tokens=40, ignore_eos=True),
+                               prompt_token_ids=prompt)
+        final, wrong = {}, []
+        while engine.has_unfinished_requests():
+            for out in engine.step():
+                if out.finished:
+                    final[out.request_id] = list(out.outputs[0].token_ids)
+            if pipeline:
+                wrong += _blocks_shared_with_different_content(engine)
+        assert not wrong, wrong
+        results[pipeline] = final
+        bm = engine.scheduler.block_manager
+        assert bm.get_num_free_gpu_blocks() == 64 and not bm._postponed
+    assert results[True] == results[False]
+    assert len({tuple(v) for v in results[True].values()}) == 3
+
+
+def test_a_block_filled_under_a_placeholder_becomes_shareable_once_its_token_is_known():
+    args = EngineArgs(model="llama-tiny", max_num_seqs=4, max_model_len=256, max_num_batched_tokens=256,
+                      swap_space=0.001, pipeline_steps=True, enable_prefix_caching=True)
+    mc, cc, pc, sc, dc = args.create_engine_configs()
+    cc.num_gpu_blocks, cc.num_cpu_blocks = 64, 8
+    engine = LLMEngine(mc, cc, pc, sc, dc, executor=FakeExecutor())
+    bm = engine.scheduler.block_manager
+    prompt = [(3 * j + 1) % VOCAB for j in range(28)]
+    engine.add_request("a", None, SamplingParams(temperature=0.0, max_tokens=30, ignore_eos=True),
+                       prompt_token_ids=prompt)
+    seq = engine.scheduler.waiting[0].get_seqs()[0]
+    while seq.get_len() < 40:
+        engine.step()
+    second = bm.block_tables[seq.seq_id][1]
+    ids = seq.get_token_ids()
+    assert PLACEHOLDER_TOKEN_ID not in ids[:32]
+    # a prompt that starts with those 32 tokens finds the block (filled by decode steps) under its content
+    assert bm.gpu_allocator.block_hash[second] == seq.hash_of_block(1)
+    engine.add_request("b", None, SamplingParams(temperature=0.0, max_tokens=2, ignore_eos=True),
+                       prompt_token_ids=ids[:32] + [5, 6, 7])
+    while not any(g.request_id == "b" for g in engine.scheduler.running):
+        engine.step()
+    other = next(g for g in engine.scheduler.running if g.request_id == "b").get_seqs()[0]
+    assert bm.block_tables[other.seq_id][:2] == bm.block_tables[seq.seq_id][:2]
+    while engine.has_unfinished_requests():
+        engine.step()
+    assert bm.get_num_free_gpu_blocks() == 64
+
+
 # ------------------------------------------------------------------ pipelined split pools
 class _PromptPending:
     """A prompt step that stays 'running on the prompt GPU' until the test lets it finish."""

@@ -190,6 +190,10 @@ class BlockSpaceManager:
         # With split pools their KV exists on the token pool only, so a later prompt that shared them would
         # have its prompt worker read blocks that were never written there: the scheduler turns this off.
         self.promote_decode_blocks = True
+        # Pipelined steps make room for a token that has not been sampled yet (the sequence ends in a placeholder).
+        # A block that becomes full that way has no content to be addressed by until the token arrives:
+        # seq id -> index of that block in the sequence's table, hashed by the next append_slot (_promote_postponed).
+        self._postponed: Dict[int, int] = {}
 
     # ------------------------------------------------------------------ prompts
     def can_allocate(self, seq_group: SequenceGroup) -> AllocStatus:
@@ -235,13 +239,23 @@ class BlockSpaceManager:
         if not self.enable_caching:
             return self.gpu_allocator.allocate()
         last = seq.num_logical_blocks - 1
-        block_hash = seq.hash_of_block(last) if self._is_last_block_full(seq) and self.promote_decode_blocks else None
+        block_hash = None
+        if self._is_last_block_full(seq) and self.promote_decode_blocks:
+            if seq.has_placeholder():
+                self._postponed[seq.seq_id] = last       # its newest token is not known yet: no content hash
+            else:
+                block_hash = seq.hash_of_block(last)
         return self.gpu_allocator.allocate(block_hash, seq.num_hashed_tokens_of_block(last))
 
     def _maybe_promote_last_block(self, seq: Sequence, block: int) -> int:
         """A block that has just become full gets its content hash, so that other sequences can share it;
         if a block with that content exists already, that one is used instead (block_manager.py:218-252)."""
         if not self.enable_caching or not self.promote_decode_blocks or not self._is_last_block_full(seq):
+            return block
+        if seq.has_placeholder():
+            # Hashing the placeholder would give every sequence with the same tokens BEFORE it the same block,
+            # whatever each of them samples next.
+            self._postponed[seq.seq_id] = seq.num_logical_blocks - 1
             return block
         new_hash = seq.hash_of_block(seq.num_logical_blocks - 1)
         if self.gpu_allocator.contains_block(new_hash):
@@ -250,10 +264,30 @@ class BlockSpaceManager:
         self.gpu_allocator.update_hash(new_hash, block)
         return block
 
+    def _promote_postponed(self, seq: Sequence) -> None:
+        """Gives a block that filled up under a placeholder its content hash once the token is there.  The
+        block keeps its place (other steps in flight already address it): if a block with that content exists
+        the two are not merged, this one just stays private."""
+        index = self._postponed.get(seq.seq_id)
+        if index is None:
+            return
+        known = seq.get_len() - (1 if seq.has_placeholder() else 0)
+        if known < (index + 1) * self.block_size:
+            return
+        del self._postponed[seq.seq_id]
+        table = self.block_tables[seq.seq_id]
+        if seq.seq_id in self._on_cpu or self.block_sliding_window is not None or index >= len(table):
+            return
+        block, new_hash = table[index], seq.hash_of_block(index)
+        if self.gpu_allocator.ref_count(block) == 1 and not self.gpu_allocator.contains_block(new_hash):
+            self.gpu_allocator.update_hash(new_hash, block)
+
     def append_slot(self, seq: Sequence) -> Optional[Tuple[int, int]]:
         """Makes room for the sequence's newest token; returns (src, dst) when the last block
         had to be copied first."""
         table = self.block_tables[seq.seq_id]
+        if self._postponed:
+            self._promote_postponed(seq)
         logical = seq.num_logical_blocks
         if len(table) < logical:
             assert len(table) == logical - 1
@@ -336,12 +370,14 @@ class BlockSpaceManager:
             return                            # already freed, or never scheduled
         self._free_table(seq.seq_id, table)
         self._on_cpu.discard(seq.seq_id)
+        self._postponed.pop(seq.seq_id, None)
 
     def reset(self) -> None:
         for seq_id, table in self.block_tables.items():
             self._free_table(seq_id, table)
         self.block_tables.clear()
         self._on_cpu.clear()
+        self._postponed.clear()
 
     # ------------------------------------------------------------------ queries
     def get_block_table(self, seq: Sequence) -> List[int]:
