@@ -3,7 +3,11 @@
 scenarios: arrivals while others decode, stop tokens, aborts at random moments, a cache small enough to preempt.
 Greedy tokens of every request that was not aborted must be identical; every block must come back.
 
-  python tools/overlap_stress.py [seeds [first seed]]
+  python tools/overlap_stress.py [seeds [first seed [prefix]]]
+
+With "prefix" the prompts start with one of three common prefixes (or repeat an earlier prompt outright) and both
+engines run with enable_prefix_caching, the base run without: shared blocks, copy-on-write and cached-prefix prompt
+steps under the same arrivals, stops, aborts and preemptions.
 """
 import random
 import sys
@@ -13,22 +17,33 @@ import torch  # noqa: E402
 from splitwise_amd import EngineArgs, LLMEngine, SamplingParams  # noqa: E402
 
 
+PREFIX = len(sys.argv) > 3 and sys.argv[3] == "prefix"
+
+
 def scenario(seed):
     rng = random.Random(seed)
     blocks = rng.choice([48, 64, 96, 400])
     reqs = []
+    heads = [[rng.randrange(512) for _ in range(n)] for n in (32, 47, 100)] if PREFIX else []
     for i in range(rng.randrange(60, 120)):
         prompt = [rng.randrange(512) for _ in range(rng.choice([1, 2, 15, 16, 17, 31, 64, 100, 150]))]
+        if PREFIX:
+            kind = rng.random()
+            if kind < 0.2 and reqs:
+                prompt = list(rng.choice(reqs)[1])
+            elif kind < 0.8:
+                prompt = (rng.choice(heads) + prompt)[:150]
         reqs.append((str(i), prompt, rng.choice([1, 2, 5, 17, 30, 60]), rng.randrange(0, 150), rng.random() < 0.3))
     aborts = {rid: arrival + rng.randrange(0, 20) for rid, _, _, arrival, _ in reqs if rng.random() < 0.15}
     return blocks, reqs, aborts
 
 
-def run(seed, overlap, stops):
+def run(seed, overlap, stops, caching=False):
     blocks, reqs, aborts = scenario(seed)
     engine = LLMEngine.from_engine_args(EngineArgs(
         model="llama-tiny", max_num_seqs=10, max_model_len=256, swap_space=0.01, num_gpu_blocks_override=blocks,
-        pipeline_steps=True, enforce_eager=False, overlap_prompt_decode=overlap, max_context_len_to_capture=256))
+        pipeline_steps=True, enforce_eager=False, overlap_prompt_decode=overlap, max_context_len_to_capture=256,
+        enable_prefix_caching=caching))
     done, aborted, call = {}, set(), 0
     while call < 170 or engine.has_unfinished_requests():
         for rid, prompt, n, arrival, want_stop in reqs:
@@ -69,31 +84,45 @@ def logits_of(tokens):
     return omodel.logits(_SD["cfg"]["architecture"], _SD["sd"], _SD["cfg"], tokens)
 
 
+def compare(seed, name, plain, ab_p, other, ab_o):
+    """-> number of requests whose tokens part ways anywhere but at a near-tie."""
+    bad = 0
+    common = [rid for rid in plain if rid in other and rid not in ab_p and rid not in ab_o]
+    diff = [rid for rid in common if plain[rid] != other[rid]]
+    print(f"seed {seed}: {name}: {len(common)} requests compared, {len(diff)} differ", flush=True)
+    # the engines batch prompts differently, and the attention kernels' summation order depends on the launch:
+    # a request may part ways at a near-tie.  The CPU model judges the first token at which they part.
+    for rid in diff:
+        prompt = next(p for r, p, *_ in scenario(seed)[1] if r == rid)
+        a, b = plain[rid], other[rid]
+        n = min(len(a), len(b))
+        k = next((i for i in range(n) if a[i] != b[i]), n)
+        if k >= n:
+            print(f"   request {rid}: lengths {len(a)} / {len(b)} with a common prefix "
+                  "(stop token at a near-tie earlier?)")
+            bad += 1
+            continue
+        row = logits_of(prompt + a[:k])[-1]
+        gap_a, gap_b = float(row.max() - row[a[k]]), float(row.max() - row[b[k]])
+        verdict = "near-tie" if max(gap_a, gap_b) < 3e-2 else "WRONG TOKEN"
+        print(f"   request {rid}: part ways at token {k}: plain {a[k]} (gap {gap_a:.4f}), {name} {b[k]} "
+              f"(gap {gap_b:.4f}) -> {verdict}")
+        bad += verdict != "near-tie"
+    return bad
+
+
 bad = 0
 first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 for seed in range(first, first + (int(sys.argv[1]) if len(sys.argv) > 1 else 6)):
     base, _, _, _ = run(seed, False, {})
     stops = {rid: toks[min(2, len(toks) - 1)] for rid, toks in base.items() if toks}
     plain, ab_p, ok_p, pre_p = run(seed, False, stops)
-    over, ab_o, ok_o, pre_o = run(seed, True, stops)
-    common = [rid for rid in plain if rid in over and rid not in ab_p and rid not in ab_o]
-    diff = [rid for rid in common if plain[rid] != over[rid]]
-    print(f"seed {seed}: {len(common)} requests compared, {len(diff)} differ, blocks back: {ok_p} {ok_o}, "
-          f"preemptions {pre_p} / {pre_o}", flush=True)
-    # the two engines batch prompts differently, and the attention kernels' summation order depends on the launch:
-    # a request may part ways at a near-tie.  The CPU model judges the first token at which they part.
-    for rid in diff:
-        prompt = next(p for r, p, *_ in scenario(seed)[1] if r == rid)
-        a, b = plain[rid], over[rid]
-        k = next(i for i in range(min(len(a), len(b))) if a[i] != b[i]) if a[:len(b)] != b[:len(a)] else min(len(a), len(b))
-        if k >= min(len(a), len(b)):
-            print(f"   request {rid}: lengths {len(a)} / {len(b)} with a common prefix (stop token at a near-tie earlier?)")
-            bad += 1
-            continue
-        row = logits_of(prompt + a[:k])[-1]
-        gap_a, gap_b = float(row.max() - row[a[k]]), float(row.max() - row[b[k]])
-        verdict = "near-tie" if max(gap_a, gap_b) < 3e-2 else "WRONG TOKEN"
-        print(f"   request {rid}: part ways at token {k}: plain {a[k]} (gap {gap_a:.4f}), overlap {b[k]} (gap {gap_b:.4f}) -> {verdict}")
-        bad += verdict != "near-tie"
+    over, ab_o, ok_o, pre_o = run(seed, True, stops, PREFIX)
+    print(f"seed {seed}: blocks back: {ok_p} {ok_o}, preemptions {pre_p} / {pre_o}", flush=True)
+    bad += compare(seed, "overlap" + (" with the prefix cache" if PREFIX else ""), plain, ab_p, over, ab_o)
     bad += (not ok_p) + (not ok_o)
+    if PREFIX:
+        cached, ab_c, ok_c, pre_c = run(seed, False, stops, True)
+        print(f"seed {seed}: pipelined with the prefix cache: blocks back: {ok_c}, preemptions {pre_c}", flush=True)
+        bad += compare(seed, "pipelined with the prefix cache", plain, ab_p, cached, ab_c) + (not ok_c)
 sys.exit(1 if bad else 0)
