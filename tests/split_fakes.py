@@ -196,9 +196,14 @@ class FakeWorker:
                 (seq_id, data), = meta.seq_data.items()
                 tokens = data.get_token_ids()
                 table = meta.block_tables[seq_id]
+                # blocks reported as computed are not written again: their content must be in the cache already,
+                # and the sampled token is then taken from what the cache holds
+                skip = len(getattr(meta, "computed_block_nums", None) or []) * self.block_size
+                self.cached_prompt_tokens = getattr(self, "cached_prompt_tokens", 0) + skip
                 for pos, tok in enumerate(tokens):
-                    self._write(table, pos, tok)
-                tok = self._agree(next_token(tokens))
+                    if pos >= skip:
+                        self._write(table, pos, tok)
+                tok = self._agree(next_token(self._read(table, len(tokens)) if skip else tokens))
                 outputs.append(SequenceGroupOutput([SequenceOutput(seq_id, tok, {tok: Logprob(0.0)})]))
             if self.mixed:
                 return SamplerOutput(outputs)

@@ -182,6 +182,42 @@ def test_prefix_caching_reuses_blocks_and_generates_like_the_cpu_model(sep, pipe
         torch.cuda.empty_cache()
 
 
+@pytest.mark.parametrize("overlap", [False, True])
+def test_the_next_turn_of_a_conversation_reuses_blocks_that_decode_steps_filled(overlap, monkeypatch):
+    """Prompt + answer + a few new tokens as the next prompt: with the prefix cache the blocks that DECODE steps
+    filled are found by content and not computed again -- in the co-located engine as in the reference, and with
+    prompt steps beside decode steps on one GPU (one cache; two pools share only prompt-written blocks).  Pipelined
+    steps on both: the block that fills up under a not-yet-sampled token gets its hash one step later.  The tokens
+    of both turns are the CPU model's."""
+    from splitwise_amd import LLM, SamplingParams, _C
+    random.seed(13)
+    llm = LLM("llama-tiny", enable_prefix_caching=True, enforce_eager=False, num_gpu_blocks_override=96,
+              max_num_seqs=8, max_model_len=512, swap_space=0.01, pipeline_steps=True, overlap_prompt_decode=overlap)
+    cached_tokens = []
+    orig = _C.ops.context_attention_fwd
+
+    def counting(q, k, v, o, k_cache, v_cache, block_tables, start_loc, seq_lens, context_lens, *a, **kw):
+        cached_tokens.append(int(context_lens.sum()))
+        return orig(q, k, v, o, k_cache, v_cache, block_tables, start_loc, seq_lens, context_lens, *a, **kw)
+
+    monkeypatch.setattr(_C.ops, "context_attention_fwd", counting)
+    vocab = llm.llm_engine.model_config.get_vocab_size()
+    first = [[random.randrange(vocab) for _ in range(n)] for n in (21, 33, 70)]
+    params = SamplingParams(temperature=0.0, max_tokens=60, ignore_eos=True)
+    outs1 = llm.generate(prompt_token_ids=first, sampling_params=params)
+    assert not cached_tokens
+    second = [p + list(o.outputs[0].token_ids) + [random.randrange(vocab) for _ in range(3)]
+              for p, o in zip(first, outs1)]
+    outs2 = llm.generate(prompt_token_ids=second, sampling_params=SamplingParams(temperature=0.0, max_tokens=12))
+    # 81, 93 and 130 tokens of history: 5, 5 and 8 full blocks, of which all but the last are reported as computed
+    layers = llm.llm_engine.model_config.hf_config["num_hidden_layers"]
+    assert sum(cached_tokens) >= layers * (4 + 4 + 7) * 16, cached_tokens
+    assert llm.llm_engine.scheduler.block_manager.get_num_free_gpu_blocks() == 96
+    _check_greedy(llm, first + second, list(outs1) + list(outs2), tol=3e-2)
+    del llm
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("quantization", ["gptq", "awq"])
 @pytest.mark.parametrize("overlap", [False, True])
 def test_int4_models_match_cpu_model(quantization, overlap):

@@ -394,3 +394,54 @@ def test_overlap_executor_runs_the_split_loop_over_one_worker(blocks, tmp_path, 
     assert (getattr(engine.scheduler, "num_preemptions", 0) > 0) == (blocks == 2)
     with pytest.raises(ValueError):
         EngineArgs(model="llama-tiny", overlap_prompt_decode=True).create_engine_configs()       # needs pipeline_steps
+
+
+def test_overlap_engine_shares_blocks_that_decode_steps_filled(tmp_path, monkeypatch):
+    """One GPU, one cache: with the prefix cache on, a later prompt that starts with an earlier request's prompt AND
+    answer (the next turn of a conversation) finds the blocks the decode steps filled and does not compute them
+    again -- as in the co-located engine, unlike two pools, where a decode step's keys and values exist on the token
+    pool only.  The stand-in worker takes a cached prompt's token from what its cache holds, so a block reported as
+    computed before it was written, or shared with other content, gives a wrong token."""
+    from split_fakes import FakeWorker
+    from splitwise_amd.executor.overlap_executor import OverlapExecutor
+    monkeypatch.setenv("SPLIT_FAKE_DIR", str(tmp_path))
+    monkeypatch.setenv("SPLIT_FAKE_BLOCKS", "48")
+    args = EngineArgs(model="llama-tiny", max_num_seqs=6, max_model_len=256, max_num_batched_tokens=512,
+                      swap_space=0.001, pipeline_steps=True, overlap_prompt_decode=True, enable_prefix_caching=True)
+    mc, cc, pc, sc, dc = args.create_engine_configs()
+    executor = OverlapExecutor(mc, cc, pc, sc, dc, worker_cls=FakeWorker)
+    engine = LLMEngine(mc, cc, pc, sc, dc, executor=executor)
+    assert engine.scheduler.block_manager.promote_decode_blocks
+
+    def generate(requests):
+        for rid, (prompt, n) in requests.items():
+            engine.add_request(rid, None, SamplingParams(temperature=0.0, max_tokens=n, ignore_eos=True),
+                               prompt_token_ids=prompt)
+        done, calls = {}, 0
+        while engine.has_unfinished_requests():
+            calls += 1
+            assert calls < 3000
+            for out in engine.step():
+                if out.finished:
+                    done[out.request_id] = list(out.outputs[0].token_ids)
+        return done
+
+    def expected(prompt, n):
+        seq = list(prompt)
+        for _ in range(n):
+            seq.append(next_token(seq))
+        return seq[len(prompt):]
+
+    first = {"a": ([(7 * j + 3) % VOCAB for j in range(21)], 60), "b": ([(5 * j + 1) % VOCAB for j in range(33)], 45)}
+    out1 = generate(first)
+    assert all(out1[rid] == expected(*first[rid]) for rid in first)
+    worker = executor.driver_worker
+    before = getattr(worker, "cached_prompt_tokens", 0)
+    # the next turn: prompt + answer + a few new tokens (and one that parts ways in the middle of the answer)
+    second = {"a2": (first["a"][0] + out1["a"] + [9, 8, 7], 20),
+              "b2": (first["b"][0] + out1["b"][:30] + [4, 4, 4, 4], 20)}
+    out2 = generate(second)
+    assert all(out2[rid] == expected(*second[rid]) for rid in second)
+    # a's 81 tokens fill 5 blocks (4 reported as computed: never the last full one), b's first 63 tokens 3
+    assert worker.cached_prompt_tokens - before >= (4 + 3) * 16
+    assert engine.scheduler.block_manager.get_num_free_gpu_blocks() == cc.num_gpu_blocks

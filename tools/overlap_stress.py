@@ -7,7 +7,8 @@ Greedy tokens of every request that was not aborted must be identical; every blo
 
 With "prefix" the prompts start with one of three common prefixes (or repeat an earlier prompt outright) and both
 engines run with enable_prefix_caching, the base run without: shared blocks, copy-on-write and cached-prefix prompt
-steps under the same arrivals, stops, aborts and preemptions.
+steps under the same arrivals, stops, aborts and preemptions; some requests get a next turn (prompt + answer + new
+tokens), which finds blocks that decode steps filled.
 """
 import random
 import sys
@@ -35,7 +36,17 @@ def scenario(seed):
                 prompt = (rng.choice(heads) + prompt)[:150]
         reqs.append((str(i), prompt, rng.choice([1, 2, 5, 17, 30, 60]), rng.randrange(0, 150), rng.random() < 0.3))
     aborts = {rid: arrival + rng.randrange(0, 20) for rid, _, _, arrival, _ in reqs if rng.random() < 0.15}
+    # next turns of a conversation: an earlier prompt, its answer (known from the seed's first run) and a few new
+    # tokens, arriving while the first turn is still running or after it: blocks that decode steps filled
+    answers = _ANSWERS.get(seed, {})
+    for rid, prompt, _, arrival, _ in list(reqs):
+        if answers.get(rid) and rid not in aborts and rng.random() < 0.3:
+            turn = (prompt + answers[rid] + [rng.randrange(512) for _ in range(3)])[:200]
+            reqs.append((rid + "+", turn, rng.choice([2, 17, 30]), arrival + rng.randrange(5, 120), False))
     return blocks, reqs, aborts
+
+
+_ANSWERS = {}
 
 
 def run(seed, overlap, stops, caching=False):
@@ -45,7 +56,7 @@ def run(seed, overlap, stops, caching=False):
         pipeline_steps=True, enforce_eager=False, overlap_prompt_decode=overlap, max_context_len_to_capture=256,
         enable_prefix_caching=caching))
     done, aborted, call = {}, set(), 0
-    while call < 170 or engine.has_unfinished_requests():
+    while call < 280 or engine.has_unfinished_requests():
         for rid, prompt, n, arrival, want_stop in reqs:
             if arrival == call:
                 stop = [stops[rid]] if (want_stop and rid in stops) else []
@@ -116,6 +127,8 @@ first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 for seed in range(first, first + (int(sys.argv[1]) if len(sys.argv) > 1 else 6)):
     base, _, _, _ = run(seed, False, {})
     stops = {rid: toks[min(2, len(toks) - 1)] for rid, toks in base.items() if toks}
+    if PREFIX:
+        _ANSWERS[seed] = base
     plain, ab_p, ok_p, pre_p = run(seed, False, stops)
     over, ab_o, ok_o, pre_o = run(seed, True, stops, PREFIX)
     print(f"seed {seed}: blocks back: {ok_p} {ok_o}, preemptions {pre_p} / {pre_o}", flush=True)

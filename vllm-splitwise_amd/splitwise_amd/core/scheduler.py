@@ -62,7 +62,8 @@ def _fcfs_order(now: float, groups: Iterable[SequenceGroup]) -> Deque[SequenceGr
 
 class Scheduler:
     def __init__(self, scheduler_config: SchedulerConfig, cache_config: CacheConfig, lora_config=None,
-                 track_prompt_blocks: bool = False, strict_reference: bool = False) -> None:
+                 track_prompt_blocks: bool = False, strict_reference: bool = False,
+                 one_cache: bool = False) -> None:
         """``strict_reference`` reproduces two behaviours of the reference that the default mode
         repairs: (1) a sequence re-admitted after preemption-by-recompute draws a NEW hand-off
         slot and its old one is never returned (vllm/core/scheduler.py:446-451 calls set_seq
@@ -87,8 +88,9 @@ class Scheduler:
             enable_caching=cache_config.enable_prefix_caching)
         # split pools: only blocks written by a PROMPT step exist on both pools (the decode steps' KV lives on
         # the token pool alone), so only those may be shared with later prompts (the reference has no such
-        # guard: ``strict_reference`` keeps its behaviour)
-        self.block_manager.promote_decode_blocks = not track_prompt_blocks or strict_reference
+        # guard: ``strict_reference`` keeps its behaviour).  ``one_cache``: the prompt side and the decode side are
+        # one GPU with one cache, so decode-filled blocks are as good as prompt-written ones.
+        self.block_manager.promote_decode_blocks = not track_prompt_blocks or strict_reference or one_cache
         self.waiting: Deque[SequenceGroup] = deque()
         self.running: Deque[SequenceGroup] = deque()
         self.swapped: Deque[SequenceGroup] = deque()

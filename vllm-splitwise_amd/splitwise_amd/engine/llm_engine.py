@@ -58,8 +58,13 @@ class LLMEngine:
         # one scheduler -- one block space, one set of hand-off slots -- per token pool ("lane"); the
         # reference's world has one (vllm/config.py:434-438)
         lanes = max(getattr(parallel_config, "num_token_pools", 1), 1)
+        # (prompt steps beside decode steps on ONE GPU: the split loop over a single cache, so what a decode step
+        # wrote is there for a later prompt step to read, as in the co-located engine)
+        self._decode_kv_shareable = (not parallel_config.sep_prompt_token
+                                     or bool(getattr(parallel_config, "one_gpu_overlap", False)))
         self.schedulers = [Scheduler(scheduler_config, cache_config, None,
-                                     track_prompt_blocks=parallel_config.sep_prompt_token) for _ in range(lanes)]
+                                     track_prompt_blocks=parallel_config.sep_prompt_token,
+                                     one_cache=self._decode_kv_shareable) for _ in range(lanes)]
         self.scheduler = self.schedulers[0] if lanes == 1 else SchedulerGroup(self.schedulers)
         # a prompt pool that keeps only the prompts in flight hands out its own block numbers, step by step
         self.staged_prompt_cache = bool(getattr(parallel_config, "staged_prompt_cache", False))
@@ -231,8 +236,7 @@ class LLMEngine:
         wall = time.time()
         scheduler = self.schedulers[lane]
         scheduled = list(scheduler_outputs.scheduled_seq_groups) if groups is None else groups
-        if self.cache_config.enable_prefix_caching and (scheduler_outputs.prompt_run
-                                                        or not self.parallel_config.sep_prompt_token):
+        if self.cache_config.enable_prefix_caching and (scheduler_outputs.prompt_run or self._decode_kv_shareable):
             # the step has written the KV of every full block of these sequences: later prompts with the
             # same leading tokens need not compute them again (llm_engine.py:543-547).  With split pools a
             # decode step's KV exists on the token pool only: a prompt worker could not read it, so only
@@ -350,7 +354,7 @@ class LLMEngine:
             scheduler.free_seq(seq)
         self._free_later[lane] = []
         reported: List[SequenceGroup] = []
-        if self.cache_config.enable_prefix_caching and not self.parallel_config.sep_prompt_token:
+        if self.cache_config.enable_prefix_caching and self._decode_kv_shareable:
             # (split pools resolve only decode steps here, and those mark nothing: see _process_model_outputs)
             for group, seq in pairs:
                 if not seq.is_finished() or seq.has_placeholder():
