@@ -84,6 +84,7 @@ class FakeWorker:
         self.model_runner = _FakeRunner()
         self.kvcache_comm_manager = _FakeCommManager() if not self.mixed else None
         self.cache = self.flags = None
+        self.cached_prompt_tokens = 0          # prompt tokens taken from blocks reported as computed
         self.peer_caches, self.peer_flag_arrays = [], []
         self.block_size = 16
         self.log: List[str] = []
@@ -199,7 +200,7 @@ class FakeWorker:
                 # blocks reported as computed are not written again: their content must be in the cache already,
                 # and the sampled token is then taken from what the cache holds
                 skip = len(getattr(meta, "computed_block_nums", None) or []) * self.block_size
-                self.cached_prompt_tokens = getattr(self, "cached_prompt_tokens", 0) + skip
+                self.cached_prompt_tokens += skip
                 for pos, tok in enumerate(tokens):
                     if pos >= skip:
                         self._write(table, pos, tok)

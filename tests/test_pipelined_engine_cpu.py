@@ -436,7 +436,7 @@ def test_overlap_engine_shares_blocks_that_decode_steps_filled(tmp_path, monkeyp
     out1 = generate(first)
     assert all(out1[rid] == expected(*first[rid]) for rid in first)
     worker = executor.driver_worker
-    before = getattr(worker, "cached_prompt_tokens", 0)
+    before = worker.cached_prompt_tokens
     # the next turn: prompt + answer + a few new tokens (and one that parts ways in the middle of the answer)
     second = {"a2": (first["a"][0] + out1["a"] + [9, 8, 7], 20),
               "b2": (first["b"][0] + out1["b"][:30] + [4, 4, 4, 4], 20)}
