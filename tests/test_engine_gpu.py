@@ -406,19 +406,22 @@ def test_one_prompt_sampled_several_ways_under_prefix_caching_and_pipelined_step
     assert results[2] == results[0]
 
 
-@pytest.mark.parametrize("pipeline,blocks", [(False, 256), (True, 256), (False, 24)])
-def test_parallel_sampling_forks_share_the_prompt_and_copy_on_write(pipeline, blocks):
+@pytest.mark.parametrize("pipeline,blocks,caching", [(False, 256, False), (True, 256, False), (False, 24, False),
+                                                     (True, 256, True), (False, 16, True)])
+def test_parallel_sampling_forks_share_the_prompt_and_copy_on_write(pipeline, blocks, caching):
     """n > 1 inside one request (vllm/engine/llm_engine.py:424-534, Scheduler.fork_seq, block_manager.py:302-309):
     the prompt step draws best_of tokens, every further sequence is a fork of the prompt sequence that shares
     its blocks until one of them writes (the last, partly filled prompt block is copied first).  With top_k = 1
     the random-sampling path is deterministic, so every one of the n outputs must equal the greedy output of the
     same prompt -- which it only does if every fork's cache holds the right keys and values.  A pipelined engine
     runs plain steps while such a request is alive and goes back to pipelined steps afterwards; with 24 blocks the
-    groups are preempted (swapped out and in again as groups)."""
+    groups are preempted (swapped out and in again as groups).  ``caching``: the same under the prefix cache, where
+    the forked requests and their greedy twins share prompt blocks by content as well, and the pipelined engine's
+    blocks that filled up under a placeholder meet the plain steps' merge of equal blocks."""
     from splitwise_amd import LLM, SamplingParams
     random.seed(6)
     llm = LLM("llama-tiny", enforce_eager=False, num_gpu_blocks_override=blocks, max_num_seqs=12, max_model_len=256,
-              swap_space=0.05, pipeline_steps=pipeline)
+              swap_space=0.05, pipeline_steps=pipeline, enable_prefix_caching=caching)
     engine = llm.llm_engine
     prompts = [[random.randrange(512) for _ in range(n)] for n in (5, 33, 64, 17, 40)]
     greedy = llm.generate(prompt_token_ids=prompts, sampling_params=SamplingParams(temperature=0.0, max_tokens=24))
@@ -454,7 +457,7 @@ def test_parallel_sampling_forks_share_the_prompt_and_copy_on_write(pipeline, bl
         same_or_near_tie(i, done[f"g{i}"].outputs[0])
     assert not engine._multi_sample_requests
     assert engine.scheduler.block_manager.get_num_free_gpu_blocks() == blocks          # every fork's blocks came back
-    if blocks == 24:
+    if blocks < 256:
         assert getattr(engine.scheduler, "num_preemptions", 0) > 0
     # diverging samples: best_of = 3 of which the 2 most likely come back, ordered by cumulative log-probability
     outs = llm.generate(prompt_token_ids=prompts[:2],
