@@ -268,3 +268,83 @@ def test_a_block_that_fills_up_is_promoted_to_its_content_hash():
     # both second blocks now hold 5 6 7 8 after the same first block: one physical block
     assert bm.get_block_table(s1)[1] == bm.get_block_table(s2)[1]
     assert bm.gpu_allocator.ref_count(bm.get_block_table(s1)[1]) == 2
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_placeholders_never_make_two_sequences_share_a_block_they_fill_differently(seed):
+    """Pipelined steps: room is made for a token before it is known (the sequence ends in a placeholder, -1), and
+    the token before it is filled in afterwards.  Random sequences over a few common prompts, each drawing its own
+    tokens: whenever two live sequences hold the same physical block at some index, the tokens they know of in it
+    must agree; reference counts equal the number of tables that hold a block; a block that filled up under a
+    placeholder is found by its content once the token is known; and everything comes back."""
+    import random
+
+    from splitwise_amd.sequence import PLACEHOLDER_TOKEN_ID
+    rng = random.Random(seed)
+    bs, blocks = 4, 64
+    bm = BlockSpaceManager(bs, blocks, 8, watermark=0, enable_caching=True)
+    heads = [[rng.randrange(3) for _ in range(n)] for n in (3, 4, 7, 8, 9)]
+    live, next_id = [], [1000 * (seed + 1)]
+
+    def check():
+        holders = {}
+        for seq in live:
+            table = bm.get_block_table(seq)
+            assert len(table) == seq.num_logical_blocks
+            ids = seq.get_token_ids()
+            for k, block in enumerate(dict.fromkeys(table)):
+                known = tuple(t for t in ids[bs * k:bs * (k + 1)] if t != PLACEHOLDER_TOKEN_ID)
+                holders.setdefault(block, []).append((k, known))
+        for block, held in holders.items():
+            assert bm.gpu_allocator.ref_count(block) == len(held), (block, held)
+            for k, known in held[1:]:
+                k0, known0 = held[0]
+                n = min(len(known), len(known0))
+                assert k == k0 and known[:n] == known0[:n], (block, held)
+
+    for _ in range(400):
+        roll = rng.random()
+        if (roll < 0.15 or not live) and len(live) < 8:
+            next_id[0] += 1
+            seq = Sequence(next_id[0], None, list(rng.choice(heads)), bs)
+            bm.allocate(SequenceGroup(str(next_id[0]), [seq], SamplingParams(), time.time()))
+            seq.status = SequenceStatus.RUNNING
+            live.append(seq)
+        elif roll < 0.22:
+            bm.free(live.pop(rng.randrange(len(live))))
+        else:
+            seq = rng.choice(live)
+            if seq.get_len() >= 40:
+                continue
+            # one pipelined step: the next token's place is made first, the previous token arrives afterwards
+            had = seq.has_placeholder()
+            if had and rng.random() < 0.5:
+                tok = rng.randrange(3)
+                seq.fill_placeholder(tok, {tok: Logprob(0.0)})
+                had = False
+            if not had:
+                seq.append_placeholder()
+                bm.append_slot(seq)
+        check()
+    # a finished sequence's full blocks can be found again by a prompt with the same tokens
+    for seq in live:
+        if seq.has_placeholder():
+            tok = rng.randrange(3)
+            seq.fill_placeholder(tok, {tok: Logprob(0.0)})
+    donor = max(live, key=lambda s: s.get_len())
+    if donor.get_len() >= 3 * bs:
+        donor.append_placeholder()
+        bm.append_slot(donor)                                  # (hashes the block that filled up one step ago)
+        ids = [t for t in donor.get_token_ids() if t != PLACEHOLDER_TOKEN_ID]
+        twin = Sequence(next_id[0] + 1, None, ids[:(len(ids) // bs) * bs] + [7], bs)
+        bm.allocate(SequenceGroup("twin", [twin], SamplingParams(), time.time()))
+        full = len(ids) // bs
+        # (the donor's own block, or an older one with the same content: blocks are hashed in place, never merged)
+        shared = sum(a == b for a, b in zip(bm.get_block_table(twin)[:full], bm.get_block_table(donor)[:full]))
+        assert shared >= 1 and all(bm.gpu_allocator.block_hash[b] == donor.hash_of_block(k)
+                                   for k, b in enumerate(bm.get_block_table(twin)[:full]))
+        live.append(twin)
+        check()
+    for seq in live:
+        bm.free(seq)
+    assert bm.get_num_free_gpu_blocks() == blocks and not bm._postponed
